@@ -1,0 +1,176 @@
+/*
+ * magi_hip.h -- C ABI of libmagi_hip.so, the MI355X (gfx950) engine for the MAGI hot path.
+ *
+ * The reference (sophiaxxiao/magi_v2) has no FFI: its boundary is the Python class surface
+ * of magi_v2.py.  Each entry point below names the reference computation it replaces
+ * (file:line relative to the reference tree).  The host-side mirror of that class lives in
+ * magi_v2_amd/api.py and binds these symbols with ctypes; INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; every array is C-contiguous fp64 (or int64 where stated) and is
+ *     owned by the caller; no pointer outlives the call except the opaque handle.
+ *   - host layout of trajectories follows the reference: X[chain][N][D] (row-major [N,D]).
+ *   - every int-returning function returns 0 on success and a negative MAGI_E_* code on
+ *     failure; magi_last_error() gives the message (pass NULL for creation failures).
+ *   - one handle per GPU; a handle is not thread-safe; different handles may be driven from
+ *     different host threads.
+ */
+#ifndef MAGI_HIP_H
+#define MAGI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct magi_handle magi_handle;
+
+enum {
+    MAGI_OK = 0,
+    MAGI_E_BADARG = -1,   /* shape / pointer / state error                              */
+    MAGI_E_HIP = -2,      /* a HIP runtime call failed                                  */
+    MAGI_E_NOTSPD = -3,   /* Cholesky met a non-positive pivot (index in the message)   */
+    MAGI_E_NAN = -4,      /* NaN in an initial state (reference asserts magi_v2.py:289-291) */
+    MAGI_E_STATE = -5     /* call order violated (e.g. sampling before set_problem)     */
+};
+
+/* compiled-in ODE drifts f(t, X, theta) with analytic Jacobians:
+ *   SEIR3: vignette.ipynb cell 3 (S implicit; theta = beta, gamma, sigma)
+ *   SEIR4: the four data columns with S explicit (data/SEIR_seed=0.csv:1)
+ *   SIRW : test_magi_script.py:19-45 (theta = beta, phi, xi, chi, kappa)          */
+enum { MAGI_DRIFT_SEIR3 = 0, MAGI_DRIFT_SEIR4 = 1, MAGI_DRIFT_SIRW = 2 };
+
+enum { MAGI_MODE_NUTS = 0, MAGI_MODE_HMC = 1 };
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+
+/* Binds device `device_id`, creates the stream.  NULL on failure (see magi_last_error(NULL)). */
+magi_handle* magi_create(int device_id);
+void magi_destroy(magi_handle* h);
+const char* magi_last_error(const magi_handle* h);
+/* "magi_hip <version> gfx950" */
+const char* magi_version(void);
+
+/* ---- kernel matrices ---------------------------------------------------------------------- */
+
+/* Replaces MAGI_v2._build_matrices (magi_v2.py:774-823), the pinv sites (magi_v2.py:126,128 /
+ * 266,268 / 449,451) and the band approximation (magi_v2.py:271-274) for all D components:
+ * Matern(nu) Kappa / p_Kappa / Kappa_pp assembly on the grid I[N], fp64 blocked Cholesky,
+ * m = p_Kappa Kappa^-1, K = Kappa_pp - p_Kappa Kappa^-1 Kappa_p, C^-1, K^-1, band mask.
+ * bandsize < 0 means dense.  The results stay resident on the device for the log-posterior
+ * and sampler calls; C_inv / m / K_inv ([D][N][N] row-major host buffers) may each be NULL
+ * when the caller does not want a host copy. */
+int magi_build_matrices(magi_handle* h, const double* I, int N, int D,
+                        const double* phi1, const double* phi2, double nu, int bandsize,
+                        double* C_inv, double* m, double* K_inv);
+
+/* The three Matern blocks alone (magi_v2.py:781-815) for one component; host outputs [N][N]. */
+int magi_matern_blocks(magi_handle* h, const double* I, int N, double phi1, double phi2, double nu,
+                       double* Kappa, double* p_Kappa, double* Kappa_pp);
+
+/* User-overwritten or golden matrices (the reference lets users overwrite C_d_invs, m_ds,
+ * K_d_invs between fit and predict, magi_v2.py:77-80).  [D][N][N] row-major.  With
+ * bandsize >= 0 entries with |i-j| > bandsize are dropped exactly as tf.linalg.band_part
+ * does (magi_v2.py:271-274) and the matrices are kept in banded storage N x (2b+1). */
+int magi_set_matrices(magi_handle* h, int N, int D, int bandsize,
+                      const double* C_inv, const double* m, const double* K_inv);
+
+/* ---- log posterior ------------------------------------------------------------------------ */
+
+/* Constants captured by the reference's log-posterior closure (magi_v2.py:294-300):
+ * mu[D] (magi_v2.py:114,259), N_ds[D] (:53), obs_idx[n_obs] = flat row-major indices into
+ * X[N][D] of the non-NaN observations (:96), y[n_obs] (:100), beta = D|I|/sum N_d (:89),
+ * LB[D] (:300), the drift and its parameter count P.  Requires matrices (for N, D). */
+int magi_set_problem(magi_handle* h, const double* mu, const double* N_ds,
+                     const int64_t* obs_idx, const double* y, int64_t n_obs,
+                     double beta, const double* LB, int drift_id, int P);
+
+/* unnormalized_log_prob (magi_v2.py:308-348) and its gradient (TF autodiff in the reference,
+ * induced by magi_v2.py:360-364) for n_chains independent states.
+ * X[n_chains][N][D], sig_pre[n_chains][D], th_pre[n_chains][P] -> logp[n_chains],
+ * gX[n_chains][N][D], gsig[n_chains][D], gth[n_chains][P] (any output may be NULL).
+ * terms, if not NULL, receives t1..t4 per chain ([n_chains][4], magi_v2.py:332-345). */
+int magi_logpost_grad(magi_handle* h, int n_chains, const double* X, const double* sig_pre,
+                      const double* th_pre, double beta_temp,
+                      double* logp, double* gX, double* gsig, double* gth, double* terms);
+
+/* ---- sampler ------------------------------------------------------------------------------ */
+
+/* Replaces the TFP wiring of predict (magi_v2.py:357-396) and LogAnnealedNUTS
+ * (magi_v2.py:838-889).  Defaults via magi_sampler_cfg_default() are the reference's. */
+typedef struct magi_sampler_cfg {
+    int32_t num_results;          /* magi_v2.py:390                                         */
+    int32_t num_burnin_steps;     /* magi_v2.py:391                                         */
+    int32_t num_adaptation_steps; /* < 0 -> int(0.8 * num_burnin_steps), magi_v2.py:365     */
+    int32_t max_tree_depth;       /* TFP default 10                                         */
+    int32_t mode;                 /* MAGI_MODE_NUTS (reference) or MAGI_MODE_HMC (fixed L)  */
+    int32_t hmc_leapfrogs;        /* L for MAGI_MODE_HMC                                    */
+    int32_t anneal;               /* 1: beta_temp(k) = max(1/ln(k+2), min_temp), :833-835   */
+    int32_t stale_cache;          /* 1: reuse the previous step's cached target/grad as TFP
+                                     does (computed at the previous temperature)            */
+    double step_size;             /* 0.1, magi_v2.py:364                                    */
+    double target_accept_prob;    /* 0.75, magi_v2.py:366                                   */
+    double max_energy_diff;       /* TFP default 1000                                       */
+    double min_temp;              /* 0.1, magi_v2.py:357                                    */
+} magi_sampler_cfg;
+
+void magi_sampler_cfg_default(magi_sampler_cfg* cfg);
+
+/* Start n_chains independent chains from pre-transformed states (the softplus-inverse inits
+ * of magi_v2.py:374-383 are formed by the host layer).  chain_ids[n_chains] (may be NULL =
+ * 0..n-1) select the Philox stream of each chain so results do not depend on how chains are
+ * sharded over GPUs.  Fails with MAGI_E_NAN when a state holds NaN (magi_v2.py:289-291). */
+int magi_sampler_init(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains,
+                      const double* X0, const double* sig_pre0, const double* th_pre0,
+                      uint64_t seed, const int64_t* chain_ids);
+
+/* Advance every chain by up to n_steps transitions (burn-in steps count); blocks until done.
+ * leapfrogs_done, if not NULL, receives the gradient evaluations taken in this call (sum over
+ * chains); kernel_ms the device time between the first and last launch of the call. */
+int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, double* kernel_ms);
+
+/* Steps completed so far per chain (burn-in included). */
+int magi_sampler_steps_done(magi_handle* h, int64_t* steps /* [n_chains] */);
+
+/* Post-burn-in samples, pre-transform (sample_results of magi_v2.py:421):
+ * X[n_chains][num_results][N][D], sig_pre[n_chains][num_results][D], th_pre[..][P]. */
+int magi_sampler_get_samples(magi_handle* h, double* X, double* sig_pre, double* th_pre);
+
+/* Per-step diagnostics for ALL steps taken so far (burn-in included), each [n_chains][n_total]
+ * with n_total = num_burnin_steps + num_results; any pointer may be NULL.  These are the
+ * NUTSKernelResults fields the reference traces (magi_v2.py:394). */
+int magi_sampler_get_diag(magi_handle* h, double* step_size, double* log_accept_ratio,
+                          int32_t* leapfrogs_taken, int32_t* tree_depth, int32_t* has_divergence,
+                          int32_t* reach_max_depth, int32_t* is_accepted,
+                          double* target_log_prob, double* energy, double* beta_temp);
+
+/* Current state of every chain (checkpoint / hand-over to the CPU oracle in tests):
+ * X[n_chains][N][D], sig_pre, th_pre, step_size[n_chains] (the dual-averaging "new step
+ * size"), beta_cache[n_chains] (temperature at which the cached target was computed). */
+int magi_sampler_get_state(magi_handle* h, double* X, double* sig_pre, double* th_pre,
+                           double* step_size, double* beta_cache);
+
+/* One-call form: init + run(num_burnin + num_results) + get_samples. */
+int magi_sample(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains,
+                const double* X0, const double* sig_pre0, const double* th_pre0,
+                uint64_t seed, const int64_t* chain_ids,
+                double* X_samps, double* sig_pre_samps, double* th_pre_samps);
+
+/* ---- instrumentation (bench.py roofline leg) ----------------------------------------------- */
+
+/* Launch one gradient evaluation (the 3 mat-vec phases + reduce) `reps` times on the handle's
+ * stream, bracketed by HIP events on that stream; phase_ms[4] receives the average device
+ * time per launch of phase 1, 2, 3 and the reduce kernel, measured in separate event-bracketed
+ * loops.  Uses the states currently on the device (n_chains as last set). */
+int magi_time_gradient(magi_handle* h, int n_chains, int reps, double* total_ms_per_eval, double* phase_ms);
+
+/* Algorithmic HBM bytes of one gradient evaluation for the current matrices and n_chains,
+ * per phase [4] (DESIGN.md section "bytes per unit"). */
+int magi_gradient_bytes(magi_handle* h, int n_chains, double* phase_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGI_HIP_H */

@@ -1,0 +1,557 @@
+// extern "C" entry points of libmagi_hip.so (see include/magi_hip.h for the contract).
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+
+#include "magi_internal.h"
+
+thread_local std::string g_magi_last_error;
+
+int magi_fail(magi_handle* h, int code, const std::string& msg) {
+    g_magi_last_error = msg;
+    if (h) h->err = msg;
+    return code;
+}
+
+namespace {
+
+const int kGraphSlots = 32;
+
+void free_dev(void* p) { if (p) (void)hipFree(p); }
+
+void free_matrices(magi_handle* h) {
+    free_dev(h->dCsym); free_dev(h->dM); free_dev(h->dMt); free_dev(h->dKsym); free_dev(h->dYobs);
+    h->dCsym = h->dM = h->dMt = h->dKsym = h->dYobs = nullptr;
+    h->have_matrices = h->have_problem = false;
+}
+
+void free_chains(magi_handle* h) {
+    DevChains& c = h->ch;
+    free_dev(c.vec); free_dev(c.ctl); free_dev(c.gctl); free_dev(c.samples);
+    free_dev(c.d_step_size); free_dev(c.d_lar); free_dev(c.d_target); free_dev(c.d_energy); free_dev(c.d_beta);
+    free_dev(c.d_leapfrogs); free_dev(c.d_depth); free_dev(c.d_flags);
+    free_dev(h->d_chain_ids); free_dev(h->d_fin);
+    c = DevChains{};
+    h->d_chain_ids = nullptr; h->d_fin = nullptr;
+    h->cap_chains = 0; h->n_chains = 0; h->samples_cap = 0; h->diag_cap = 0;
+    h->sampler_ready = false;
+}
+
+void drop_graph(magi_handle* h) {
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    h->graph_exec = nullptr; h->graph = nullptr; h->graph_valid = false;
+}
+
+// host <-> device state layout: host X[N][D] row-major  <->  device comp-major [D][N] | sig | th
+void pack_state(const DevProblem& pb, const double* X, const double* sp, const double* tp, double* q) {
+    for (int d = 0; d < pb.D; ++d)
+        for (int i = 0; i < pb.N; ++i) q[(size_t)d * pb.N + i] = X[(size_t)i * pb.D + d];
+    for (int d = 0; d < pb.D; ++d) q[pb.ND + d] = sp[d];
+    for (int p = 0; p < pb.P; ++p) q[pb.ND + pb.D + p] = tp[p];
+    for (int e = pb.dim; e < pb.dimp; ++e) q[e] = 0.0;
+}
+
+void unpack_state(const DevProblem& pb, const double* q, double scale, double* X, double* sp, double* tp) {
+    if (X)
+        for (int d = 0; d < pb.D; ++d)
+            for (int i = 0; i < pb.N; ++i) X[(size_t)i * pb.D + d] = scale * q[(size_t)d * pb.N + i];
+    if (sp) for (int d = 0; d < pb.D; ++d) sp[d] = scale * q[pb.ND + d];
+    if (tp) for (int p = 0; p < pb.P; ++p) tp[p] = scale * q[pb.ND + pb.D + p];
+}
+
+int upload_states(magi_handle* h, int n, const double* X, const double* sp, const double* tp) {
+    const DevProblem& pb = h->pb;
+    std::vector<double> q((size_t)pb.dimp);
+    for (int c = 0; c < n; ++c) {
+        pack_state(pb, X + (size_t)c * pb.ND, sp + (size_t)c * pb.D, tp + (size_t)c * pb.P, q.data());
+        for (int e = 0; e < pb.dim; ++e)
+            if (std::isnan(q[e])) return magi_fail(h, MAGI_E_NAN, "NaN in the initial state of chain " + std::to_string(c));
+        MAGI_HIP_CHECK(h, hipMemcpy(h->ch.vec + vec_off(pb, c, V_Q), q.data(), sizeof(double) * pb.dimp, hipMemcpyHostToDevice));
+    }
+    return MAGI_OK;
+}
+
+int build_graph(magi_handle* h) {
+    drop_graph(h);
+    MAGI_HIP_CHECK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int rc = MAGI_OK;
+    for (int s = 0; s < kGraphSlots && rc == MAGI_OK; ++s) {
+        rc = magi_launch_gradient(h, h->n_chains, h->stream);
+        if (rc == MAGI_OK) rc = magi_launch_tail(h, h->n_chains, h->stream);
+    }
+    hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
+    if (rc != MAGI_OK) return rc;
+    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    MAGI_HIP_CHECK(h, hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+    h->graph_valid = true;
+    h->graph_slots = kGraphSlots;
+    return MAGI_OK;
+}
+
+}  // namespace
+
+int magi_ensure_chains(magi_handle* h, int n) {
+    if (!h->have_matrices || !h->have_problem) return magi_fail(h, MAGI_E_STATE, "set matrices and problem first");
+    if (n <= 0 || n > 4096) return magi_fail(h, MAGI_E_BADARG, "n_chains out of range");
+    if (n > h->cap_chains) {
+        free_chains(h);
+        const size_t vbytes = (size_t)n * V_COUNT * h->pb.dimp * sizeof(double);
+        MAGI_HIP_CHECK(h, hipMalloc(&h->ch.vec, vbytes));
+        MAGI_HIP_CHECK(h, hipMemset(h->ch.vec, 0, vbytes));
+        MAGI_HIP_CHECK(h, hipMalloc(&h->ch.ctl, sizeof(ChainCtl) * n));
+        MAGI_HIP_CHECK(h, hipMemset(h->ch.ctl, 0, sizeof(ChainCtl) * n));
+        MAGI_HIP_CHECK(h, hipMalloc(&h->ch.gctl, sizeof(GlobalCtl)));
+        MAGI_HIP_CHECK(h, hipMemset(h->ch.gctl, 0, sizeof(GlobalCtl)));
+        MAGI_HIP_CHECK(h, hipMalloc(&h->d_chain_ids, sizeof(long long) * n));
+        MAGI_HIP_CHECK(h, hipMalloc(&h->d_fin, sizeof(double) * 8 * n));
+        h->cap_chains = n;
+    }
+    if (h->n_chains != n) drop_graph(h);
+    h->n_chains = n;
+    h->ch.n_chains = n;
+    return MAGI_OK;
+}
+
+extern "C" {
+
+const char* magi_version(void) { return "magi_hip 0.1.0 gfx950"; }
+
+const char* magi_last_error(const magi_handle* h) { return h ? h->err.c_str() : g_magi_last_error.c_str(); }
+
+magi_handle* magi_create(int device_id) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_magi_last_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+        return nullptr;
+    }
+    if (device_id < 0 || device_id >= ndev) {
+        g_magi_last_error = "device_id out of range";
+        return nullptr;
+    }
+    if ((e = hipSetDevice(device_id)) != hipSuccess) {
+        g_magi_last_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return nullptr;
+    }
+    magi_handle* h = new magi_handle();
+    h->device = device_id;
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipHostMalloc((void**)&h->h_gctl, sizeof(GlobalCtl) * 4, hipHostMallocDefault)) != hipSuccess) {
+        g_magi_last_error = std::string("handle setup: ") + hipGetErrorString(e);
+        delete h;
+        return nullptr;
+    }
+    for (int i = 0; i < 4; ++i) (void)hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming);
+    (void)hipEventCreate(&h->ev_t0);
+    (void)hipEventCreate(&h->ev_t1);
+    return h;
+}
+
+void magi_destroy(magi_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    drop_graph(h);
+    free_chains(h);
+    free_matrices(h);
+    for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->ev_t0) (void)hipEventDestroy(h->ev_t0);
+    if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
+    if (h->h_gctl) (void)hipHostFree(h->h_gctl);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int magi_set_matrices(magi_handle* h, int N, int D, int bandsize, const double* C_inv, const double* m,
+                      const double* K_inv) {
+    if (!h) return MAGI_E_BADARG;
+    if (!C_inv || !m || !K_inv) return magi_fail(h, MAGI_E_BADARG, "null matrix pointer");
+    if (N < 2 || D < 1 || D > MAGI_MAX_D) return magi_fail(h, MAGI_E_BADARG, "need N >= 2 and 1 <= D <= 4");
+    (void)hipSetDevice(h->device);
+    const size_t bytes = (size_t)D * N * N * sizeof(double);
+    double *dC = nullptr, *dm = nullptr, *dK = nullptr;
+    MAGI_HIP_CHECK(h, hipMalloc(&dC, bytes));
+    MAGI_HIP_CHECK(h, hipMalloc(&dm, bytes));
+    MAGI_HIP_CHECK(h, hipMalloc(&dK, bytes));
+    MAGI_HIP_CHECK(h, hipMemcpy(dC, C_inv, bytes, hipMemcpyHostToDevice));
+    MAGI_HIP_CHECK(h, hipMemcpy(dm, m, bytes, hipMemcpyHostToDevice));
+    MAGI_HIP_CHECK(h, hipMemcpy(dK, K_inv, bytes, hipMemcpyHostToDevice));
+    int rc = magi_pack_matrices(h, N, D, bandsize, dC, dm, dK);
+    (void)hipStreamSynchronize(h->stream);
+    free_dev(dC); free_dev(dm); free_dev(dK);
+    return rc;
+}
+
+int magi_build_matrices(magi_handle* h, const double* I, int N, int D, const double* phi1, const double* phi2,
+                        double nu, int bandsize, double* C_inv, double* m, double* K_inv) {
+    if (!h) return MAGI_E_BADARG;
+    if (!I || !phi1 || !phi2) return magi_fail(h, MAGI_E_BADARG, "null pointer");
+    if (N < 2 || D < 1 || D > MAGI_MAX_D) return magi_fail(h, MAGI_E_BADARG, "need N >= 2 and 1 <= D <= 4");
+    if (!(nu > 1.0)) return magi_fail(h, MAGI_E_BADARG, "nu must exceed 1 (once-differentiable Matern)");
+    (void)hipSetDevice(h->device);
+    return magi_build_matrices_device(h, I, N, D, phi1, phi2, nu, bandsize, C_inv, m, K_inv);
+}
+
+int magi_matern_blocks(magi_handle* h, const double* I, int N, double phi1, double phi2, double nu, double* Kappa,
+                       double* p_Kappa, double* Kappa_pp) {
+    if (!h) return MAGI_E_BADARG;
+    if (!I || N < 2) return magi_fail(h, MAGI_E_BADARG, "bad grid");
+    (void)hipSetDevice(h->device);
+    return magi_matern_blocks_device(h, I, N, phi1, phi2, nu, Kappa, p_Kappa, Kappa_pp);
+}
+
+int magi_set_problem(magi_handle* h, const double* mu, const double* N_ds, const int64_t* obs_idx, const double* y,
+                     int64_t n_obs, double beta, const double* LB, int drift_id, int P) {
+    if (!h) return MAGI_E_BADARG;
+    if (!h->have_matrices) return magi_fail(h, MAGI_E_STATE, "matrices must be set before the problem");
+    if (!mu || !N_ds || !LB || (n_obs > 0 && (!obs_idx || !y))) return magi_fail(h, MAGI_E_BADARG, "null pointer");
+    DevProblem& pb = h->pb;
+    int needD, needP;
+    switch (drift_id) {
+    case MAGI_DRIFT_SEIR3: needD = 3; needP = 3; break;
+    case MAGI_DRIFT_SEIR4: needD = 4; needP = 3; break;
+    case MAGI_DRIFT_SIRW: needD = 4; needP = 5; break;
+    default: return magi_fail(h, MAGI_E_BADARG, "unknown drift id");
+    }
+    if (pb.D != needD || P != needP)
+        return magi_fail(h, MAGI_E_BADARG, "drift expects D=" + std::to_string(needD) + ", P=" + std::to_string(needP));
+    (void)hipSetDevice(h->device);
+    const int N = pb.N, D = pb.D;
+    std::vector<double> yobs((size_t)N * D, std::nan(""));
+    for (int64_t k = 0; k < n_obs; ++k) {
+        const int64_t idx = obs_idx[k];
+        if (idx < 0 || idx >= (int64_t)N * D) return magi_fail(h, MAGI_E_BADARG, "obs_idx out of range");
+        const int i = (int)(idx / D), d = (int)(idx % D);          // flat row-major index into X[N][D]
+        yobs[(size_t)d * N + i] = y[k];
+    }
+    free_dev(h->dYobs);
+    h->dYobs = nullptr;
+    MAGI_HIP_CHECK(h, hipMalloc(&h->dYobs, sizeof(double) * N * D));
+    MAGI_HIP_CHECK(h, hipMemcpy(h->dYobs, yobs.data(), sizeof(double) * N * D, hipMemcpyHostToDevice));
+    pb.yobs = h->dYobs;
+    pb.P = P;
+    pb.drift = drift_id;
+    pb.dim = pb.ND + D + P;
+    pb.dimp = (pb.dim + 7) & ~7;
+    pb.beta_inv = 1.0 / beta;
+    for (int d = 0; d < MAGI_MAX_D; ++d) {
+        pb.mu[d] = d < D ? mu[d] : 0.0;
+        pb.N_ds[d] = d < D ? N_ds[d] : 0.0;
+        pb.LB[d] = d < D ? LB[d] : 0.0;
+    }
+    h->have_problem = true;
+    free_chains(h);          // dimp may have changed
+    drop_graph(h);
+    return MAGI_OK;
+}
+
+int magi_logpost_grad(magi_handle* h, int n_chains, const double* X, const double* sig_pre, const double* th_pre,
+                      double beta_temp, double* logp, double* gX, double* gsig, double* gth, double* terms) {
+    if (!h) return MAGI_E_BADARG;
+    if (!X || !sig_pre || !th_pre) return magi_fail(h, MAGI_E_BADARG, "null state pointer");
+    (void)hipSetDevice(h->device);
+    int rc = magi_ensure_chains(h, n_chains);
+    if (rc) return rc;
+    h->sampler_ready = false;
+    const DevProblem& pb = h->pb;
+    if ((rc = upload_states(h, n_chains, X, sig_pre, th_pre))) return rc;
+    MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.gctl, 0, sizeof(GlobalCtl), h->stream));
+    if ((rc = magi_launch_gradient(h, n_chains, h->stream))) return rc;
+    if ((rc = magi_launch_finalize(h, n_chains, h->d_fin, h->stream))) return rc;
+    MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    std::vector<double> fin((size_t)8 * n_chains), g((size_t)pb.dimp);
+    MAGI_HIP_CHECK(h, hipMemcpy(fin.data(), h->d_fin, sizeof(double) * 8 * n_chains, hipMemcpyDeviceToHost));
+    for (int c = 0; c < n_chains; ++c) {
+        if (logp) logp[c] = beta_temp * fin[(size_t)c * 8];
+        if (terms) for (int k = 0; k < 4; ++k) terms[(size_t)c * 4 + k] = fin[(size_t)c * 8 + 1 + k];
+        if (gX || gsig || gth) {
+            MAGI_HIP_CHECK(h, hipMemcpy(g.data(), h->ch.vec + vec_off(pb, c, V_G), sizeof(double) * pb.dimp, hipMemcpyDeviceToHost));
+            unpack_state(pb, g.data(), beta_temp, gX ? gX + (size_t)c * pb.ND : nullptr,
+                         gsig ? gsig + (size_t)c * pb.D : nullptr, gth ? gth + (size_t)c * pb.P : nullptr);
+        }
+    }
+    return MAGI_OK;
+}
+
+void magi_sampler_cfg_default(magi_sampler_cfg* cfg) {
+    if (!cfg) return;
+    cfg->num_results = 1000;
+    cfg->num_burnin_steps = 1000;
+    cfg->num_adaptation_steps = -1;
+    cfg->max_tree_depth = 10;
+    cfg->mode = MAGI_MODE_NUTS;
+    cfg->hmc_leapfrogs = 32;
+    cfg->anneal = 1;
+    cfg->stale_cache = 1;
+    cfg->step_size = 0.1;
+    cfg->target_accept_prob = 0.75;
+    cfg->max_energy_diff = 1000.0;
+    cfg->min_temp = 0.1;
+}
+
+int magi_sampler_init(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains, const double* X0, const double* sig_pre0,
+                      const double* th_pre0, uint64_t seed, const int64_t* chain_ids) {
+    if (!h) return MAGI_E_BADARG;
+    if (!cfg || !X0 || !sig_pre0 || !th_pre0) return magi_fail(h, MAGI_E_BADARG, "null pointer");
+    if (cfg->num_results < 0 || cfg->num_burnin_steps < 0 || cfg->num_results + cfg->num_burnin_steps <= 0)
+        return magi_fail(h, MAGI_E_BADARG, "need num_results + num_burnin_steps > 0");
+    if (cfg->max_tree_depth < 1 || cfg->max_tree_depth > MAGI_MAX_DEPTH)
+        return magi_fail(h, MAGI_E_BADARG, "max_tree_depth must be in [1, 12]");
+    if (cfg->mode != MAGI_MODE_NUTS) return magi_fail(h, MAGI_E_BADARG, "only MAGI_MODE_NUTS is implemented");
+    if (!(cfg->step_size > 0.0)) return magi_fail(h, MAGI_E_BADARG, "step_size must be positive");
+    (void)hipSetDevice(h->device);
+    int rc = magi_ensure_chains(h, n_chains);
+    if (rc) return rc;
+    const DevProblem& pb = h->pb;
+    SamplerCfgDev& c = h->cfg;
+    c.total = cfg->num_results + cfg->num_burnin_steps;
+    c.burnin = cfg->num_burnin_steps;
+    c.n_adapt = cfg->num_adaptation_steps >= 0 ? cfg->num_adaptation_steps : (int)(0.8 * cfg->num_burnin_steps);
+    c.max_depth = cfg->max_tree_depth;
+    c.mode = cfg->mode;
+    c.hmc_L = cfg->hmc_leapfrogs;
+    c.anneal = cfg->anneal;
+    c.stale = cfg->stale_cache;
+    c.step_size = cfg->step_size;
+    c.target_accept = cfg->target_accept_prob;
+    c.max_energy_diff = cfg->max_energy_diff;
+    c.min_temp = cfg->min_temp;
+    c.seed = seed;
+    h->num_results = cfg->num_results;
+
+    // output buffers
+    const size_t need_s = (size_t)n_chains * std::max(1, cfg->num_results) * pb.dimp;
+    if (need_s > h->samples_cap) {
+        free_dev(h->ch.samples);
+        h->ch.samples = nullptr;
+        MAGI_HIP_CHECK(h, hipMalloc(&h->ch.samples, need_s * sizeof(double)));
+        h->samples_cap = need_s;
+    }
+    const size_t need_d = (size_t)n_chains * c.total;
+    if (need_d > h->diag_cap) {
+        DevChains& d = h->ch;
+        free_dev(d.d_step_size); free_dev(d.d_lar); free_dev(d.d_target); free_dev(d.d_energy); free_dev(d.d_beta);
+        free_dev(d.d_leapfrogs); free_dev(d.d_depth); free_dev(d.d_flags);
+        MAGI_HIP_CHECK(h, hipMalloc(&d.d_step_size, need_d * sizeof(double)));
+        MAGI_HIP_CHECK(h, hipMalloc(&d.d_lar, need_d * sizeof(double)));
+        MAGI_HIP_CHECK(h, hipMalloc(&d.d_target, need_d * sizeof(double)));
+        MAGI_HIP_CHECK(h, hipMalloc(&d.d_energy, need_d * sizeof(double)));
+        MAGI_HIP_CHECK(h, hipMalloc(&d.d_beta, need_d * sizeof(double)));
+        MAGI_HIP_CHECK(h, hipMalloc(&d.d_leapfrogs, need_d * sizeof(int)));
+        MAGI_HIP_CHECK(h, hipMalloc(&d.d_depth, need_d * sizeof(int)));
+        MAGI_HIP_CHECK(h, hipMalloc(&d.d_flags, need_d * sizeof(int)));
+        h->diag_cap = need_d;
+    }
+    drop_graph(h);   // kernel arguments (cfg, buffers) are baked into the captured graph
+
+    if ((rc = upload_states(h, n_chains, X0, sig_pre0, th_pre0))) return rc;
+    std::vector<long long> ids(n_chains);
+    for (int i = 0; i < n_chains; ++i) ids[i] = chain_ids ? (long long)chain_ids[i] : (long long)i;
+    MAGI_HIP_CHECK(h, hipMemcpy(h->d_chain_ids, ids.data(), sizeof(long long) * n_chains, hipMemcpyHostToDevice));
+    if ((rc = magi_launch_init_chains(h, h->d_chain_ids, h->stream))) return rc;
+    // bootstrap_results: one gradient at the initial state (the tail stores it as the proposal)
+    if ((rc = magi_launch_gradient(h, n_chains, h->stream))) return rc;
+    if ((rc = magi_launch_tail(h, n_chains, h->stream))) return rc;
+    MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    h->epoch = 0;
+    h->sampler_ready = true;
+    return MAGI_OK;
+}
+
+int magi_sampler_steps_done(magi_handle* h, int64_t* steps) {
+    if (!h || !steps) return MAGI_E_BADARG;
+    if (!h->sampler_ready) return magi_fail(h, MAGI_E_STATE, "sampler not initialised");
+    (void)hipSetDevice(h->device);
+    std::vector<ChainCtl> ctl(h->n_chains);
+    MAGI_HIP_CHECK(h, hipMemcpy(ctl.data(), h->ch.ctl, sizeof(ChainCtl) * h->n_chains, hipMemcpyDeviceToHost));
+    for (int i = 0; i < h->n_chains; ++i) steps[i] = ctl[i].k;
+    return MAGI_OK;
+}
+
+int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, double* kernel_ms) {
+    if (!h) return MAGI_E_BADARG;
+    if (!h->sampler_ready) return magi_fail(h, MAGI_E_STATE, "sampler not initialised");
+    if (n_steps <= 0) return magi_fail(h, MAGI_E_BADARG, "n_steps must be positive");
+    (void)hipSetDevice(h->device);
+    int rc;
+    if (!h->graph_valid && (rc = build_graph(h))) return rc;
+
+    std::vector<ChainCtl> ctl(h->n_chains);
+    MAGI_HIP_CHECK(h, hipMemcpy(ctl.data(), h->ch.ctl, sizeof(ChainCtl) * h->n_chains, hipMemcpyDeviceToHost));
+    long long lf0 = 0;
+    int kmin = h->cfg.total;
+    for (auto& c : ctl) { lf0 += c.total_leapfrogs; kmin = std::min(kmin, c.k); }
+
+    GlobalCtl g{};
+    g.done_chains = 0;
+    g.n_chains = h->n_chains;
+    g.all_done = 0;
+    g.stop_k = std::min(h->cfg.total, kmin + n_steps);
+    g.epoch = ++h->epoch;
+    MAGI_HIP_CHECK(h, hipMemcpyAsync(h->ch.gctl, &g, sizeof(GlobalCtl), hipMemcpyHostToDevice, h->stream));
+    MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // &g is pageable stack memory
+    MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t0, h->stream));
+
+    // pump: keep two graph launches in flight; after each, snapshot the control block
+    const int depth = 2;
+    long long issued = 0, retired = 0;
+    bool done = false;
+    const long long max_graphs = 1ll << 40;
+    while (!done) {
+        while (issued - retired < depth && issued < max_graphs) {
+            const int slot = (int)(issued % 4);
+            MAGI_HIP_CHECK(h, hipGraphLaunch(h->graph_exec, h->stream));
+            MAGI_HIP_CHECK(h, hipMemcpyAsync(&h->h_gctl[slot], h->ch.gctl, sizeof(GlobalCtl), hipMemcpyDeviceToHost, h->stream));
+            MAGI_HIP_CHECK(h, hipEventRecord(h->ev[slot], h->stream));
+            ++issued;
+        }
+        const int slot = (int)(retired % 4);
+        MAGI_HIP_CHECK(h, hipEventSynchronize(h->ev[slot]));
+        if (h->h_gctl[slot].all_done) done = true;
+        ++retired;
+    }
+    MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t1, h->stream));
+    MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    if (kernel_ms) {
+        float ms = 0.f;
+        MAGI_HIP_CHECK(h, hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
+        *kernel_ms = ms;
+    }
+    if (leapfrogs_done) {
+        MAGI_HIP_CHECK(h, hipMemcpy(ctl.data(), h->ch.ctl, sizeof(ChainCtl) * h->n_chains, hipMemcpyDeviceToHost));
+        long long lf1 = 0;
+        for (auto& c : ctl) lf1 += c.total_leapfrogs;
+        *leapfrogs_done = lf1 - lf0;
+    }
+    return MAGI_OK;
+}
+
+int magi_sampler_get_samples(magi_handle* h, double* X, double* sig_pre, double* th_pre) {
+    if (!h) return MAGI_E_BADARG;
+    if (!h->sampler_ready) return magi_fail(h, MAGI_E_STATE, "sampler not initialised");
+    (void)hipSetDevice(h->device);
+    const DevProblem& pb = h->pb;
+    const int R = h->num_results;
+    std::vector<double> buf((size_t)R * pb.dimp);
+    for (int c = 0; c < h->n_chains; ++c) {
+        if (R == 0) break;
+        MAGI_HIP_CHECK(h, hipMemcpy(buf.data(), h->ch.samples + (size_t)c * R * pb.dimp, sizeof(double) * R * pb.dimp, hipMemcpyDeviceToHost));
+        for (int s = 0; s < R; ++s) {
+            const size_t o = (size_t)c * R + s;
+            unpack_state(pb, buf.data() + (size_t)s * pb.dimp, 1.0, X ? X + o * pb.ND : nullptr,
+                         sig_pre ? sig_pre + o * pb.D : nullptr, th_pre ? th_pre + o * pb.P : nullptr);
+        }
+    }
+    return MAGI_OK;
+}
+
+int magi_sampler_get_diag(magi_handle* h, double* step_size, double* log_accept_ratio, int32_t* leapfrogs_taken,
+                          int32_t* tree_depth, int32_t* has_divergence, int32_t* reach_max_depth, int32_t* is_accepted,
+                          double* target_log_prob, double* energy, double* beta_temp) {
+    if (!h) return MAGI_E_BADARG;
+    if (!h->sampler_ready) return magi_fail(h, MAGI_E_STATE, "sampler not initialised");
+    (void)hipSetDevice(h->device);
+    const size_t n = (size_t)h->n_chains * h->cfg.total;
+    const DevChains& d = h->ch;
+    if (step_size) MAGI_HIP_CHECK(h, hipMemcpy(step_size, d.d_step_size, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (log_accept_ratio) MAGI_HIP_CHECK(h, hipMemcpy(log_accept_ratio, d.d_lar, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (target_log_prob) MAGI_HIP_CHECK(h, hipMemcpy(target_log_prob, d.d_target, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (energy) MAGI_HIP_CHECK(h, hipMemcpy(energy, d.d_energy, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (beta_temp) MAGI_HIP_CHECK(h, hipMemcpy(beta_temp, d.d_beta, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (leapfrogs_taken) MAGI_HIP_CHECK(h, hipMemcpy(leapfrogs_taken, d.d_leapfrogs, n * sizeof(int), hipMemcpyDeviceToHost));
+    if (tree_depth) MAGI_HIP_CHECK(h, hipMemcpy(tree_depth, d.d_depth, n * sizeof(int), hipMemcpyDeviceToHost));
+    if (has_divergence || reach_max_depth || is_accepted) {
+        std::vector<int> f(n);
+        MAGI_HIP_CHECK(h, hipMemcpy(f.data(), d.d_flags, n * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) {
+            if (has_divergence) has_divergence[i] = f[i] & 1;
+            if (reach_max_depth) reach_max_depth[i] = (f[i] >> 1) & 1;
+            if (is_accepted) is_accepted[i] = (f[i] >> 2) & 1;
+        }
+    }
+    return MAGI_OK;
+}
+
+int magi_sampler_get_state(magi_handle* h, double* X, double* sig_pre, double* th_pre, double* step_size, double* beta_cache) {
+    if (!h) return MAGI_E_BADARG;
+    if (!h->sampler_ready) return magi_fail(h, MAGI_E_STATE, "sampler not initialised");
+    (void)hipSetDevice(h->device);
+    const DevProblem& pb = h->pb;
+    std::vector<double> q((size_t)pb.dimp);
+    std::vector<ChainCtl> ctl(h->n_chains);
+    MAGI_HIP_CHECK(h, hipMemcpy(ctl.data(), h->ch.ctl, sizeof(ChainCtl) * h->n_chains, hipMemcpyDeviceToHost));
+    for (int c = 0; c < h->n_chains; ++c) {
+        MAGI_HIP_CHECK(h, hipMemcpy(q.data(), h->ch.vec + vec_off(pb, c, V_CANDQ), sizeof(double) * pb.dimp, hipMemcpyDeviceToHost));
+        unpack_state(pb, q.data(), 1.0, X ? X + (size_t)c * pb.ND : nullptr, sig_pre ? sig_pre + (size_t)c * pb.D : nullptr,
+                     th_pre ? th_pre + (size_t)c * pb.P : nullptr);
+        if (step_size) step_size[c] = ctl[c].da_step_size;
+        if (beta_cache) beta_cache[c] = ctl[c].beta_cache;
+    }
+    return MAGI_OK;
+}
+
+int magi_sample(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains, const double* X0, const double* sig_pre0,
+                const double* th_pre0, uint64_t seed, const int64_t* chain_ids, double* X_samps, double* sig_pre_samps,
+                double* th_pre_samps) {
+    int rc = magi_sampler_init(h, cfg, n_chains, X0, sig_pre0, th_pre0, seed, chain_ids);
+    if (rc) return rc;
+    if ((rc = magi_sampler_run(h, cfg->num_results + cfg->num_burnin_steps, nullptr, nullptr))) return rc;
+    return magi_sampler_get_samples(h, X_samps, sig_pre_samps, th_pre_samps);
+}
+
+int magi_gradient_bytes(magi_handle* h, int n_chains, double* phase_bytes) {
+    if (!h || !phase_bytes) return MAGI_E_BADARG;
+    if (!h->have_matrices) return magi_fail(h, MAGI_E_STATE, "no matrices");
+    const DevProblem& pb = h->pb;
+    const double W = pb.band < 0 ? (double)pb.N : (double)(2 * pb.band + 1);
+    const double mat = (double)pb.D * pb.N * W * 8.0;      // one matrix stack, algorithmic (unpadded) bytes
+    const double vec = (double)n_chains * pb.N * pb.D * 8.0;
+    phase_bytes[0] = 2.0 * mat + 3.0 * vec;   // Csym, M ; read X, write Cx, r
+    phase_bytes[1] = 1.0 * mat + 2.0 * vec;   // Ksym    ; read r, write Kr
+    phase_bytes[2] = 1.0 * mat + 5.0 * vec;   // Mt      ; read Kr, X, Cx, yobs, write gX
+    phase_bytes[3] = 5.0 * vec;               // reduce  ; read X, Cx, r, Kr, yobs
+    return MAGI_OK;
+}
+
+int magi_time_gradient(magi_handle* h, int n_chains, int reps, double* total_ms_per_eval, double* phase_ms) {
+    if (!h) return MAGI_E_BADARG;
+    if (reps <= 0) return magi_fail(h, MAGI_E_BADARG, "reps must be positive");
+    (void)hipSetDevice(h->device);
+    int rc = magi_ensure_chains(h, n_chains);
+    if (rc) return rc;
+    MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.gctl, 0, sizeof(GlobalCtl), h->stream));
+    float ms = 0.f;
+    // warm
+    for (int i = 0; i < 3; ++i) {
+        if ((rc = magi_launch_gradient(h, n_chains, h->stream))) return rc;
+        if ((rc = magi_launch_finalize(h, n_chains, h->d_fin, h->stream))) return rc;
+    }
+    MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t0, h->stream));
+    for (int i = 0; i < reps; ++i) {
+        if ((rc = magi_launch_gradient(h, n_chains, h->stream))) return rc;
+        if ((rc = magi_launch_finalize(h, n_chains, h->d_fin, h->stream))) return rc;
+    }
+    MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t1, h->stream));
+    MAGI_HIP_CHECK(h, hipEventSynchronize(h->ev_t1));
+    MAGI_HIP_CHECK(h, hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
+    if (total_ms_per_eval) *total_ms_per_eval = ms / reps;
+    if (phase_ms) {
+        for (int ph = 1; ph <= 4; ++ph) {
+            MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t0, h->stream));
+            for (int i = 0; i < reps; ++i) {
+                if (ph <= 3) rc = magi_launch_phase(h, ph, n_chains, h->stream);
+                else rc = magi_launch_finalize(h, n_chains, h->d_fin, h->stream);
+                if (rc) return rc;
+            }
+            MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t1, h->stream));
+            MAGI_HIP_CHECK(h, hipEventSynchronize(h->ev_t1));
+            MAGI_HIP_CHECK(h, hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
+            phase_ms[ph - 1] = ms / reps;
+        }
+    }
+    return MAGI_OK;
+}
+
+}  // extern "C"

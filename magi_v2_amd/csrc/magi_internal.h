@@ -1,0 +1,463 @@
+// Internal declarations shared by the HIP translation units of libmagi_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/magi_hip.h"
+
+#define MAGI_MAX_D 4        // compiled-in drifts have D <= 4, P <= 5
+#define MAGI_MAX_P 6
+#define MAGI_MAX_DEPTH 12   // checkpoint slots for the iterative NUTS U-turn checks
+#define MAGI_TAIL_THREADS 1024
+#define MAGI_WAVE 64
+
+// ------------------------------------------------------------------------------------------
+// Device-visible problem description (passed by value to kernels)
+// ------------------------------------------------------------------------------------------
+struct DevProblem {
+    int N, D, P;
+    int ld;        // row pitch (doubles) of the four matrices; even
+    int band;      // -1 dense; else half-width b, rows hold columns [i-b, i+b]
+    int drift;
+    int ND;        // N*D
+    int dim;       // N*D + D + P
+    int dimp;      // dim rounded up to a multiple of 8
+    double beta_inv;                       // 1.0 / beta              (magi_v2.py:348)
+    double mu[MAGI_MAX_D];                 // magi_v2.py:114
+    double N_ds[MAGI_MAX_D];               // magi_v2.py:53
+    double LB[MAGI_MAX_D];                 // magi_v2.py:300
+    const double* Csym;   // [D][N][ld]  (C^-1 + C^-T)/2
+    const double* M;      // [D][N][ld]  m
+    const double* Mt;     // [D][N][ld]  m^T
+    const double* Ksym;   // [D][N][ld]  (K^-1 + K^-T)/2
+    const double* yobs;   // [D][N], NaN = not observed        (magi_v2.py:96-100)
+};
+
+// Per-chain vector slots (each dimp doubles) -------------------------------------------------
+enum VecSlot {
+    V_Q = 0,     // current leaf position: X comp-major [D][N], sigma_pre[D], theta_pre[P]
+    V_P,         // momentum (holds the half-step momentum while a gradient is in flight)
+    V_G,         // UNtempered gradient of L at V_Q
+    V_CX,        // Csym * xc           [D][N]
+    V_R,         // f - m xc            [D][N]
+    V_KR,        // Ksym * r            [D][N]
+    V_PL, V_QL, V_GL,       // left end of the trajectory
+    V_PR, V_QR, V_GR,       // right end
+    V_CANDQ, V_CANDG,       // trajectory-level proposal
+    V_SUBQ, V_SUBG,         // subtree-level proposal
+    V_RHO, V_RHOSUB,        // momentum sums (generalised U-turn)
+    V_CKP0,                 // MAGI_MAX_DEPTH checkpoint momenta
+    V_CKRHO0 = V_CKP0 + MAGI_MAX_DEPTH,
+    V_COUNT = V_CKRHO0 + MAGI_MAX_DEPTH
+};
+
+enum ChainPhase { PH_INIT = 0, PH_LEAF = 1, PH_IDLE = 2 };
+
+// Per-chain scalar state of the device-resident sampler ---------------------------------------
+struct ChainCtl {
+    int phase;
+    int k;            // index of the transition in progress (0-based, burn-in included)
+    int depth;        // doublings finished in this transition
+    int it;           // leaf index inside the current subtree
+    int nsteps;       // leaves in the current subtree (1 << depth)
+    int dir;          // +1 forward / -1 backward
+    int leaf_ctr;     // leaves so far in this transition (RNG counter)
+    int cont;         // subtree still growing
+    int nd;           // no divergence so far (subtree running value)
+    int not_div;      // no divergence, committed at subtree ends
+    int is_accepted;
+    int lf_count;     // leapfrogs committed in this transition
+    int sub_lf;
+    int da_step;
+    int done_epoch;   // last run epoch in which this chain reported itself idle
+    int pad0;
+    long long chain_id;
+    long long total_leapfrogs;
+    double eps;         // step size of this transition (> 0)
+    double beta_k;      // temperature of this transition          (magi_v2.py:855)
+    double beta_cache;  // temperature the cached target/grad of the proposal were computed at
+    double init_energy;
+    double e_sum_sub, e_sum;
+    double cand_L, cand_energy, cand_weight, cand_bfac;
+    double sub_L, sub_energy, sub_weight;
+    double L_cur;
+    double LL, LR, bfacL, bfacR;
+    double bfac_cur;
+    double da_step_size, da_error_sum, da_log_avg, da_log_shrink;
+};
+
+struct SamplerCfgDev {
+    int total, burnin, n_adapt, max_depth, mode, hmc_L, anneal, stale;
+    double step_size, target_accept, max_energy_diff, min_temp;
+    unsigned long long seed;
+};
+
+struct GlobalCtl {
+    int done_chains;   // chains idle in the current run epoch
+    int n_chains;
+    int all_done;      // every chain idle: the mat-vec kernels and the tail return immediately
+    int stop_k;        // chains pause once they have finished this many transitions
+    int epoch;         // incremented by the host at every magi_sampler_run
+    int pad[3];
+};
+
+struct DevChains {
+    double* vec;          // [n_chains][V_COUNT][dimp]
+    ChainCtl* ctl;        // [n_chains]
+    GlobalCtl* gctl;
+    int n_chains;
+    // outputs
+    double* samples;      // [n_chains][num_results][dimp]
+    double* d_step_size;  // diag arrays [n_chains][total]
+    double* d_lar;
+    double* d_target;
+    double* d_energy;
+    double* d_beta;
+    int* d_leapfrogs;
+    int* d_depth;
+    int* d_flags;         // bit0 has_divergence, bit1 reach_max_depth, bit2 is_accepted
+};
+
+__host__ __device__ inline size_t vec_off(const DevProblem& pb, int chain, int slot) {
+    return ((size_t)chain * V_COUNT + (size_t)slot) * (size_t)pb.dimp;
+}
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011), identical to oracle/magi_oracle.py::philox4x32
+// ------------------------------------------------------------------------------------------
+struct Philox4 { unsigned int x, y, z, w; };
+
+__host__ __device__ inline Philox4 philox4x32_10(unsigned int c0, unsigned int c1, unsigned int c2,
+                                                 unsigned int c3, unsigned long long key) {
+    unsigned int k0 = (unsigned int)(key & 0xFFFFFFFFull), k1 = (unsigned int)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned long long p0 = 0xD2511F53ull * (unsigned long long)c0;
+        unsigned long long p1 = 0xCD9E8D57ull * (unsigned long long)c2;
+        unsigned int hi0 = (unsigned int)(p0 >> 32), lo0 = (unsigned int)p0;
+        unsigned int hi1 = (unsigned int)(p1 >> 32), lo1 = (unsigned int)p1;
+        unsigned int n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return Philox4{c0, c1, c2, c3};
+}
+
+__host__ __device__ inline double u01_53(unsigned int hi, unsigned int lo) {
+    unsigned long long x = (((unsigned long long)hi << 32) | (unsigned long long)lo) >> 11;
+    return ((double)x + 0.5) * 1.1102230246251565e-16;   // 2^-53
+}
+
+enum { STREAM_MOMENTUM = 0, STREAM_DIRECTION = 1, STREAM_LEAF = 2, STREAM_MERGE = 3, STREAM_HMC = 4 };
+
+__device__ inline double rng_uniform(unsigned int index, unsigned int step, unsigned int chain,
+                                     unsigned int stream, unsigned long long key) {
+    Philox4 r = philox4x32_10(index, step, chain, stream, key);
+    return u01_53(r.x, r.y);
+}
+
+__device__ inline double rng_normal_elem(unsigned int e, unsigned int step, unsigned int chain,
+                                         unsigned long long key) {
+    Philox4 r = philox4x32_10(e >> 1, step, chain, STREAM_MOMENTUM, key);
+    double u1 = u01_53(r.x, r.y), u2 = u01_53(r.z, r.w);
+    double rad = sqrt(-2.0 * log(u1));
+    double ang = 2.0 * 3.141592653589793 * u2;
+    return (e & 1) ? rad * sin(ang) : rad * cos(ang);
+}
+
+// ------------------------------------------------------------------------------------------
+// scalar helpers
+// ------------------------------------------------------------------------------------------
+__device__ inline double softplus_ref(double x) { return log(1.0 + exp(x)); }   // magi_v2.py:318
+__device__ inline double sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+__device__ inline double logaddexp(double a, double b) {
+    if (a == -INFINITY && b == -INFINITY) return -INFINITY;
+    double t = a - b;
+    if (t > 0) return a + log1p(exp(-t));
+    if (t <= 0) return b + log1p(exp(t));
+    return t;   // NaN
+}
+
+__device__ inline double temperature(int step, double min_temp) {   // magi_v2.py:833-835
+    return fmax(1.0 / log((double)step + 2.0), min_temp);
+}
+
+// ------------------------------------------------------------------------------------------
+// Drifts.  x[] = state at one grid point, th[] = softplus'ed parameters.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double drift_f(int drift, int d, const double* x, const double* th) {
+    switch (drift) {
+    case MAGI_DRIFT_SEIR3: {   // vignette.ipynb cell 3
+        double E = x[0], I = x[1], R = x[2], S = 1.0 - ((E + I) + R);
+        if (d == 0) return (th[0] * S * I) - (th[2] * E);
+        if (d == 1) return (th[2] * E) - (th[1] * I);
+        return th[1] * I;
+    }
+    case MAGI_DRIFT_SEIR4: {
+        double S = x[0], E = x[1], I = x[2];
+        if (d == 0) return -th[0] * S * I;
+        if (d == 1) return th[0] * S * I - th[2] * E;
+        if (d == 2) return th[2] * E - th[1] * I;
+        return th[1] * I;
+    }
+    default: {                 // MAGI_DRIFT_SIRW, test_magi_script.py:19-45
+        double S = x[0], I = x[1], R = x[2], W = x[3];
+        if (d == 0) return -th[0] * S * I + th[4] * W;
+        if (d == 1) return th[0] * S * I - th[1] * I;
+        if (d == 2) return th[1] * I - th[2] * R + th[3] * I * W;
+        return th[2] * R - th[3] * I * W - th[4] * W;
+    }
+    }
+}
+
+// sum_d' g[d'] * d f_d' / d x_d   (column d of the Jacobian contracted with g)
+__device__ __forceinline__ double drift_jt_g(int drift, int d, const double* x, const double* th, const double* g) {
+    switch (drift) {
+    case MAGI_DRIFT_SEIR3: {
+        double E = x[0], I = x[1], R = x[2], S = 1.0 - ((E + I) + R);
+        double b = th[0], gm = th[1], s = th[2];
+        if (d == 0) return g[0] * (-b * I - s) + g[1] * s;
+        if (d == 1) return g[0] * (b * S - b * I) - g[1] * gm + g[2] * gm;
+        return -g[0] * b * I;
+    }
+    case MAGI_DRIFT_SEIR4: {
+        double S = x[0], I = x[2];
+        double b = th[0], gm = th[1], s = th[2];
+        if (d == 0) return (g[1] - g[0]) * b * I;
+        if (d == 1) return (g[2] - g[1]) * s;
+        if (d == 2) return (g[1] - g[0]) * b * S + (g[3] - g[2]) * gm;
+        return 0.0;
+    }
+    default: {
+        double S = x[0], I = x[1], W = x[3];
+        double be = th[0], ph = th[1], xi = th[2], ch = th[3], ka = th[4];
+        if (d == 0) return (g[1] - g[0]) * be * I;
+        if (d == 1) return -g[0] * be * S + g[1] * (be * S - ph) + g[2] * (ph + ch * W) - g[3] * ch * W;
+        if (d == 2) return (g[3] - g[2]) * xi;
+        return g[0] * ka + g[2] * ch * I + g[3] * (-ch * I - ka);
+    }
+    }
+}
+
+// out[p] += sum_d g[d] * d f_d / d theta_p
+__device__ __forceinline__ void drift_tt_g_acc(int drift, const double (&x)[MAGI_MAX_D], const double (&th)[MAGI_MAX_P],
+                                               const double (&g)[MAGI_MAX_D], double (&out)[MAGI_MAX_P]) {
+    // every case fills the same five scalars so the accumulation below keeps static indices
+    double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0, o4 = 0.0;
+    switch (drift) {
+    case MAGI_DRIFT_SEIR3: {
+        const double E = x[0], I = x[1], R = x[2], S = 1.0 - ((E + I) + R);
+        o0 = g[0] * S * I;
+        o1 = (g[2] - g[1]) * I;
+        o2 = (g[1] - g[0]) * E;
+        break;
+    }
+    case MAGI_DRIFT_SEIR4: {
+        const double S = x[0], E = x[1], I = x[2];
+        o0 = (g[1] - g[0]) * S * I;
+        o1 = (g[3] - g[2]) * I;
+        o2 = (g[2] - g[1]) * E;
+        break;
+    }
+    default: {
+        const double S = x[0], I = x[1], R = x[2], W = x[3];
+        o0 = (g[1] - g[0]) * S * I;
+        o1 = (g[2] - g[1]) * I;
+        o2 = (g[3] - g[2]) * R;
+        o3 = (g[2] - g[3]) * I * W;
+        o4 = (g[0] - g[3]) * W;
+        break;
+    }
+    }
+    out[0] += o0; out[1] += o1; out[2] += o2; out[3] += o3; out[4] += o4;
+}
+
+// ------------------------------------------------------------------------------------------
+// reductions: 64-lane butterfly, then a fixed-order sum over the block's waves (deterministic)
+// ------------------------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int K>
+__device__ inline void block_sum(double (&v)[K], double* sh /* [K][16] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double s = wave_sum(v[k]);
+        if (lane == 0) sh[k * 16 + wave] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += sh[k * 16 + w];
+        v[k] = s;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// Reduce step of one gradient evaluation (all threads of the block must call it).
+// Reads V_Q, V_CX, V_R, V_KR of the chain, writes the sigma_pre / theta_pre parts of V_G and
+// returns the UNtempered log posterior L and t1..t4 of magi_v2.py:332-345.
+// ------------------------------------------------------------------------------------------
+struct FinalizeOut { double L, t1, t2, t3, t4; };
+
+__device__ inline FinalizeOut finalize_gradient(const DevProblem& pb, double* vb, double* sh) {
+    const int N = pb.N, D = pb.D, P = pb.P, ND = pb.ND, dimp = pb.dimp;
+    const double* q = vb + (size_t)V_Q * dimp;
+    const double* Cx = vb + (size_t)V_CX * dimp;
+    const double* r = vb + (size_t)V_R * dimp;
+    const double* Kr = vb + (size_t)V_KR * dimp;
+    double* g = vb + (size_t)V_G * dimp;
+
+    double th[MAGI_MAX_P], tpre[MAGI_MAX_P], spre[MAGI_MAX_D];
+#pragma unroll
+    for (int p = 0; p < MAGI_MAX_P; ++p) {
+        tpre[p] = (p < P) ? q[ND + D + p] : 0.0;
+        th[p] = (p < P) ? softplus_ref(tpre[p]) : 0.0;
+    }
+#pragma unroll
+    for (int d = 0; d < MAGI_MAX_D; ++d) spre[d] = (d < D) ? q[ND + d] : 0.0;
+
+    constexpr int K = 2 + MAGI_MAX_D + MAGI_MAX_P;
+    double t1s = 0.0, t2s = 0.0, ss[MAGI_MAX_D], tp[MAGI_MAX_P];
+#pragma unroll
+    for (int d = 0; d < MAGI_MAX_D; ++d) ss[d] = 0.0;
+#pragma unroll
+    for (int p = 0; p < MAGI_MAX_P; ++p) tp[p] = 0.0;
+
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        double x[MAGI_MAX_D], g2[MAGI_MAX_D];
+#pragma unroll
+        for (int d = 0; d < MAGI_MAX_D; ++d) {
+            if (d < D) {
+                const int idx = d * N + i;
+                const double xv = q[idx];
+                x[d] = xv;
+                t1s = fma(xv - pb.mu[d], Cx[idx], t1s);
+                const double kr = Kr[idx];
+                t2s = fma(r[idx], kr, t2s);
+                g2[d] = 2.0 * kr;
+                const double y = pb.yobs[idx];
+                if (!isnan(y)) { const double df = xv - y; ss[d] = fma(df, df, ss[d]); }
+            } else { x[d] = 0.0; g2[d] = 0.0; }
+        }
+        drift_tt_g_acc(pb.drift, x, th, g2, tp);
+    }
+    double red[K];
+    red[0] = t1s;
+    red[1] = t2s;
+#pragma unroll
+    for (int d = 0; d < MAGI_MAX_D; ++d) red[2 + d] = ss[d];
+#pragma unroll
+    for (int p = 0; p < MAGI_MAX_P; ++p) red[2 + MAGI_MAX_D + p] = tp[p];
+    block_sum<K>(red, sh);
+
+    FinalizeOut o;
+    o.t1 = red[0];
+    o.t2 = red[1];
+    double t3 = 0.0, t4 = 0.0, ljs = 0.0, ljt = 0.0;
+#pragma unroll
+    for (int d = 0; d < MAGI_MAX_D; ++d) {
+        if (d < D) {
+            const double sp = softplus_ref(spre[d]);
+            const double s2 = sp + pb.LB[d];
+            t3 += pb.N_ds[d] * log(2.0 * 3.141592653589793 * s2);
+            t4 += red[2 + d] * (1.0 / s2);
+            ljs += spre[d] - sp;
+            const double sg = sigmoid(spre[d]);
+            const double dsig = pb.N_ds[d] / s2 - red[2 + d] / (s2 * s2);
+            if (threadIdx.x == 0) g[ND + d] = -0.5 * dsig * sg + (1.0 - sg);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < MAGI_MAX_P; ++p) {
+        if (p < P) {
+            ljt += tpre[p] - softplus_ref(tpre[p]);
+            const double sg = sigmoid(tpre[p]);
+            if (threadIdx.x == 0) g[ND + D + p] = -0.5 * pb.beta_inv * red[2 + MAGI_MAX_D + p] * sg + (1.0 - sg);
+        }
+    }
+    o.t3 = t3;
+    o.t4 = t4;
+    o.L = -0.5 * ((pb.beta_inv * (o.t1 + o.t2)) + (t3 + t4)) + ljs + ljt;
+    __syncthreads();   // V_G complete for the whole block
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------
+// Host-side handle
+// ------------------------------------------------------------------------------------------
+struct magi_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // matrices
+    bool have_matrices = false;
+    bool have_problem = false;
+    DevProblem pb{};
+    double *dCsym = nullptr, *dM = nullptr, *dMt = nullptr, *dKsym = nullptr, *dYobs = nullptr;
+    size_t mat_elems = 0;
+
+    // chains
+    int n_chains = 0;
+    int cap_chains = 0;
+    DevChains ch{};
+    SamplerCfgDev cfg{};
+    bool sampler_ready = false;
+    int num_results = 0;
+    // graph of G leapfrog slots
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_slots = 0;
+    int graph_chains = 0;
+    bool graph_valid = false;
+    GlobalCtl* h_gctl = nullptr;     // pinned, 4 snapshots
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    int epoch = 0;
+    long long* d_chain_ids = nullptr;
+    double* d_fin = nullptr;         // [cap_chains][8] finalize outputs
+    size_t samples_cap = 0, diag_cap = 0;
+};
+
+// error helpers -------------------------------------------------------------------------------
+extern thread_local std::string g_magi_last_error;
+int magi_fail(magi_handle* h, int code, const std::string& msg);
+
+#define MAGI_HIP_CHECK(h, expr)                                                                   \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return magi_fail((h), MAGI_E_HIP,                                                     \
+                             std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + \
+                                 ":" + std::to_string(__LINE__) + ")");                           \
+    } while (0)
+
+// launchers implemented in logpost.hip / sampler.hip ---------------------------------------------
+int magi_launch_gradient(magi_handle* h, int n_chains, hipStream_t s);        // phases 1-3
+int magi_launch_phase(magi_handle* h, int phase, int n_chains, hipStream_t s);
+int magi_launch_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s);
+int magi_launch_tail(magi_handle* h, int n_chains, hipStream_t s);
+int magi_launch_init_chains(magi_handle* h, const long long* d_chain_ids, hipStream_t s);
+int magi_ensure_chains(magi_handle* h, int n_chains);
+// build.hip: dense device matrices -> packed device storage (sym / transpose / band)
+int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double* dC_inv, const double* dM,
+                       const double* dK_inv);
+int magi_build_matrices_device(magi_handle* h, const double* I, int N, int D, const double* phi1,
+                               const double* phi2, double nu, int bandsize, double* C_inv, double* m,
+                               double* K_inv);
+int magi_matern_blocks_device(magi_handle* h, const double* I, int N, double phi1, double phi2, double nu,
+                              double* Kappa, double* p_Kappa, double* Kappa_pp);

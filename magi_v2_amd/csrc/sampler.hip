@@ -1,0 +1,345 @@
+// Device-resident NUTS / dual-averaging / annealing state machine.
+//
+// Replaces the TFP wiring of MAGI_v2.predict (magi_v2.py:357-396): NoUTurnSampler(step_size=0.1)
+// inside DualAveragingStepSizeAdaptation(int(0.8*burnin), 0.75), wrapped by LogAnnealedNUTS
+// (magi_v2.py:838-889, temperature schedule :833-835).  TFP itself is not in the reference tree;
+// its published algorithm (iterative tree doubling with multinomial sampling and the generalised
+// U-turn test, max_tree_depth 10, max_energy_diff 1000; Nesterov dual averaging) is restated in
+// oracle/magi_oracle.py and mirrored here decision for decision, with a shared Philox4x32-10 RNG.
+//
+// MI355X design: a leapfrog is the static kernel sequence [phase1, phase2, phase3, tail].  The
+// tail (one 1024-thread workgroup per chain) finishes the gradient, completes the momentum
+// update, does all tree bookkeeping (multinomial proposal, checkpointed U-turn tests, doubling,
+// merge, transition end, dual averaging, temperature, next momentum draw) and writes the NEXT
+// position to evaluate.  No decision ever returns to the host, so the host only replays one
+// hipGraph of G leapfrog slots and polls a done counter; chains advance asynchronously, each
+// using every slot.  Energies follow TFP: energy = target - 0.5 p.p  (minus the Hamiltonian).
+#include "magi_internal.h"
+
+namespace {
+
+struct TailVecs {
+    double *q, *p, *g, *pL, *qL, *gL, *pR, *qR, *gR, *candq, *candg, *subq, *subg, *rho, *rhosub, *ckp, *ckrho;
+};
+
+__device__ inline TailVecs tail_vecs(const DevProblem& pb, double* vb) {
+    const size_t s = pb.dimp;
+    TailVecs v;
+    v.q = vb + V_Q * s; v.p = vb + V_P * s; v.g = vb + V_G * s;
+    v.pL = vb + V_PL * s; v.qL = vb + V_QL * s; v.gL = vb + V_GL * s;
+    v.pR = vb + V_PR * s; v.qR = vb + V_QR * s; v.gR = vb + V_GR * s;
+    v.candq = vb + V_CANDQ * s; v.candg = vb + V_CANDG * s;
+    v.subq = vb + V_SUBQ * s; v.subg = vb + V_SUBG * s;
+    v.rho = vb + V_RHO * s; v.rhosub = vb + V_RHOSUB * s;
+    v.ckp = vb + V_CKP0 * s; v.ckrho = vb + V_CKRHO0 * s;
+    return v;
+}
+
+// Start a doubling from the end selected by the direction bit and take the first half/full step
+// (leapfrog with identity mass: p_half = p + eps/2 * grad ; q' = q + eps * p_half).
+__device__ inline void begin_doubling(const DevProblem& pb, const SamplerCfgDev& cfg, ChainCtl& c, const TailVecs& v) {
+    const int dim = pb.dim;
+    Philox4 r = philox4x32_10((unsigned)c.depth, (unsigned)c.k, (unsigned)c.chain_id, STREAM_DIRECTION, cfg.seed);
+    const bool fwd = (r.x & 1u) != 0;
+    c.dir = fwd ? 1 : -1;
+    const double* pe = fwd ? v.pR : v.pL;
+    const double* qe = fwd ? v.qR : v.qL;
+    const double* ge = fwd ? v.gR : v.gL;
+    const double bf = fwd ? c.bfacR : c.bfacL;
+    const double eps = c.dir * c.eps;
+    const double hs = 0.5 * eps * bf;
+    for (int e = threadIdx.x; e < dim; e += blockDim.x) {
+        const double ph = pe[e] + hs * ge[e];
+        v.p[e] = ph;
+        v.q[e] = qe[e] + eps * ph;
+        v.rhosub[e] = 0.0;
+    }
+    c.nsteps = 1 << c.depth;
+    c.it = 0;
+    c.sub_weight = -INFINITY;
+    c.e_sum_sub = 0.0;
+    c.sub_lf = 0;
+    c.cont = 1;
+    c.nd = c.not_div;
+    c.phase = PH_LEAF;
+}
+
+// Start transition k: temperature, momentum draw, both ends = current proposal, first doubling.
+__device__ inline void begin_sample(const DevProblem& pb, const SamplerCfgDev& cfg, ChainCtl& c, const TailVecs& v, double* sh) {
+    const int dim = pb.dim;
+    c.beta_k = cfg.anneal ? temperature(c.k, cfg.min_temp) : 1.0;
+    const double bc = cfg.stale ? c.beta_cache : c.beta_k;
+    c.eps = c.da_step_size;
+    double pp[1] = {0.0};
+    for (int e = threadIdx.x; e < dim; e += blockDim.x) {
+        const double z = rng_normal_elem((unsigned)e, (unsigned)c.k, (unsigned)c.chain_id, cfg.seed);
+        pp[0] = fma(z, z, pp[0]);
+        v.pL[e] = z; v.pR[e] = z; v.rho[e] = z;
+        const double qq = v.candq[e], gg = v.candg[e];
+        v.qL[e] = qq; v.qR[e] = qq;
+        v.gL[e] = gg; v.gR[e] = gg;
+    }
+    block_sum<1>(pp, sh);
+    c.init_energy = bc * c.cand_L - 0.5 * pp[0];
+    c.LL = c.LR = c.cand_L;
+    c.bfacL = c.bfacR = bc;
+    c.cand_bfac = bc;
+    c.cand_energy = c.init_energy;
+    c.cand_weight = 0.0;
+    c.e_sum = 0.0;
+    c.lf_count = 0;
+    c.not_div = 1;
+    c.is_accepted = 0;
+    c.depth = 0;
+    c.leaf_ctr = 0;
+    begin_doubling(pb, cfg, c, v);
+}
+
+// DualAveragingStepSizeAdaptation.one_step after the inner NUTS step (oracle: dual_averaging_update)
+__device__ inline void dual_averaging(const SamplerCfgDev& cfg, ChainCtl& c, double log_accept_ratio) {
+    double lap = isfinite(log_accept_ratio) ? log_accept_ratio : -INFINITY;
+    lap = fmin(lap, 0.0);
+    const double accept = (lap > -INFINITY) ? exp(lap) : 0.0;
+    const int prev = c.da_step;
+    const double t = (double)(prev + 1);
+    double new_err = c.da_error_sum + cfg.target_accept - accept;
+    const double soft_t = 10.0 + t;                              // step_count_smoothing
+    const double new_log_step = c.da_log_shrink - (new_err * sqrt(t)) / (soft_t * 0.05);   // exploration_shrinkage
+    const double eta = pow(t, -0.75);                            // decay_rate
+    double new_log_avg = eta * new_log_step + (1.0 - eta) * c.da_log_avg;
+    double new_ss;
+    if (prev < cfg.n_adapt) new_ss = exp(new_log_step);
+    else if (prev > cfg.n_adapt) new_ss = c.da_step_size;
+    else new_ss = exp(new_log_avg);
+    if (prev > cfg.n_adapt) { new_err = c.da_error_sum; new_log_avg = c.da_log_avg; }
+    c.da_step_size = new_ss;
+    c.da_error_sum = new_err;
+    c.da_log_avg = new_log_avg;
+    c.da_step = prev + 1;
+}
+
+__global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevChains ch, SamplerCfgDev cfg) {
+    __shared__ double sh[(2 + MAGI_MAX_D + MAGI_MAX_P) * 16];
+    if (ch.gctl->all_done) return;
+    const int chain = blockIdx.x;
+    ChainCtl c = ch.ctl[chain];
+    const int dim = pb.dim;
+    const int stop_k = min(ch.gctl->stop_k, cfg.total);
+    const int epoch = ch.gctl->epoch;
+    double* vb = ch.vec + vec_off(pb, chain, 0);
+    const TailVecs v = tail_vecs(pb, vb);
+
+    if (c.phase == PH_IDLE) {
+        if (c.k < stop_k) {            // resumed by a later magi_sampler_run
+            begin_sample(pb, cfg, c, v, sh);
+            if (threadIdx.x == 0) ch.ctl[chain] = c;
+        } else if (c.done_epoch != epoch) {
+            c.done_epoch = epoch;
+            if (threadIdx.x == 0) {
+                ch.ctl[chain] = c;
+                const int done = atomicAdd(&ch.gctl->done_chains, 1) + 1;
+                if (done >= ch.gctl->n_chains) ch.gctl->all_done = 1;
+            }
+        }
+        return;
+    }
+
+    // ---- 1. finish the gradient at V_Q ---------------------------------------------------------
+    const FinalizeOut fo = finalize_gradient(pb, vb, sh);
+    const double L = fo.L;
+
+    if (c.phase == PH_INIT) {
+        // bootstrap_results: target / gradient at the initial state, cached at beta_temp(0)
+        for (int e = threadIdx.x; e < dim; e += blockDim.x) { v.candq[e] = v.q[e]; v.candg[e] = v.g[e]; }
+        c.cand_L = L;
+        c.beta_cache = cfg.anneal ? temperature(0, cfg.min_temp) : 1.0;
+        __syncthreads();
+        if (c.k < stop_k) begin_sample(pb, cfg, c, v, sh);
+        else c.phase = PH_IDLE;
+        if (threadIdx.x == 0) ch.ctl[chain] = c;
+        return;
+    }
+
+    // ---- 2. leaf: complete the momentum update, sums, checkpoints -------------------------------
+    c.L_cur = L;
+    c.total_leapfrogs += 1;
+    const double eps = c.dir * c.eps;
+    const double hs = 0.5 * eps * c.beta_k;
+    const int it = c.it;
+    const bool even = (it & 1) == 0;
+    double* ckp_w = v.ckp + (size_t)__popc((unsigned)it) * pb.dimp;
+    double* ckr_w = v.ckrho + (size_t)__popc((unsigned)it) * pb.dimp;
+    double pp[1] = {0.0};
+    for (int e = threadIdx.x; e < dim; e += blockDim.x) {
+        const double pn = v.p[e] + hs * v.g[e];
+        v.p[e] = pn;
+        const double rs = v.rhosub[e] + pn;
+        v.rhosub[e] = rs;
+        pp[0] = fma(pn, pn, pp[0]);
+        if (even) { ckp_w[e] = pn; ckr_w[e] = rs; }
+    }
+    block_sum<1>(pp, sh);
+
+    bool no_u = true;
+    if (!even) {
+        for (int kk = 1; ((it + 1) & ((1 << kk) - 1)) == 0 && (1 << kk) <= c.nsteps; ++kk) {
+            const int left = it + 1 - (1 << kk);
+            const double* cp = v.ckp + (size_t)__popc((unsigned)left) * pb.dimp;
+            const double* cr = v.ckrho + (size_t)__popc((unsigned)left) * pb.dimp;
+            double dots[2] = {0.0, 0.0};
+            for (int e = threadIdx.x; e < dim; e += blockDim.x) {
+                const double df = v.rhosub[e] - cr[e];
+                dots[0] = fma(df, cp[e], dots[0]);
+                dots[1] = fma(df, v.p[e], dots[1]);
+            }
+            block_sum<2>(dots, sh);
+            no_u = no_u && (dots[0] > 0.0) && (dots[1] > 0.0);
+        }
+    }
+
+    // ---- 3. energy, multinomial proposal inside the subtree -----------------------------------------
+    double energy = c.beta_k * L - 0.5 * pp[0];
+    if (isnan(energy)) energy = -INFINITY;
+    const double ediff = energy - c.init_energy;
+    const bool not_divergent = (-ediff < cfg.max_energy_diff);
+    {
+        const double wsum = logaddexp(c.sub_weight, ediff);
+        const double thresh = ediff - wsum;
+        const double u = log1p(-rng_uniform((unsigned)c.leaf_ctr, (unsigned)c.k, (unsigned)c.chain_id, STREAM_LEAF, cfg.seed));
+        c.leaf_ctr += 1;
+        if (u <= thresh) {
+            for (int e = threadIdx.x; e < dim; e += blockDim.x) { v.subq[e] = v.q[e]; v.subg[e] = v.g[e]; }
+            c.sub_L = L;
+            c.sub_energy = energy;
+        }
+        c.sub_weight = wsum;
+    }
+    const bool cont_tree = not_divergent && (c.cont != 0);
+    c.cont = (no_u && cont_tree) ? 1 : 0;
+    c.nd = (c.nd && not_divergent) ? 1 : 0;
+    if (cont_tree) c.e_sum_sub += exp(fmin(ediff, 0.0));
+    c.sub_lf += 1;
+    c.it = it + 1;
+
+    if (c.it < c.nsteps && c.cont) {
+        // ---- 4a. next leaf of the same subtree: half step + position update -----------------------
+        for (int e = threadIdx.x; e < dim; e += blockDim.x) {
+            const double ph = v.p[e] + hs * v.g[e];
+            v.p[e] = ph;
+            v.q[e] = v.q[e] + eps * ph;
+        }
+        if (threadIdx.x == 0) ch.ctl[chain] = c;
+        return;
+    }
+
+    // ---- 4b. subtree finished: merge into the trajectory (biased progressive sampling) --------------
+    __syncthreads();
+    {
+        const double tree_weight = c.cont ? c.sub_weight : -INFINITY;
+        const double wsum = logaddexp(tree_weight, c.cand_weight);
+        const double thresh = tree_weight - c.cand_weight;
+        const double u = log1p(-rng_uniform((unsigned)c.depth, (unsigned)c.k, (unsigned)c.chain_id, STREAM_MERGE, cfg.seed));
+        const bool choose = (u <= thresh) && (c.cont != 0);
+        double* pe = (c.dir > 0) ? v.pR : v.pL;
+        double* qe = (c.dir > 0) ? v.qR : v.qL;
+        double* ge = (c.dir > 0) ? v.gR : v.gL;
+        const double* po = (c.dir > 0) ? v.pL : v.pR;    // the other end
+        double dots[2] = {0.0, 0.0};
+        for (int e = threadIdx.x; e < dim; e += blockDim.x) {
+            if (choose) { v.candq[e] = v.subq[e]; v.candg[e] = v.subg[e]; }
+            const double pn = v.p[e];
+            pe[e] = pn; qe[e] = v.q[e]; ge[e] = v.g[e];
+            const double rr = v.rho[e] + v.rhosub[e];
+            v.rho[e] = rr;
+            dots[0] = fma(rr, po[e], dots[0]);
+            dots[1] = fma(rr, pn, dots[1]);
+        }
+        block_sum<2>(dots, sh);
+        if (choose) { c.cand_L = c.sub_L; c.cand_energy = c.sub_energy; c.cand_bfac = c.beta_k; c.is_accepted = 1; }
+        c.cand_weight = wsum;
+        if (c.dir > 0) { c.LR = c.L_cur; c.bfacR = c.beta_k; } else { c.LL = c.L_cur; c.bfacL = c.beta_k; }
+        const bool no_u_traj = (dots[0] > 0.0) && (dots[1] > 0.0);
+        c.e_sum += c.e_sum_sub;
+        c.lf_count += c.sub_lf;
+        c.not_div = c.nd;
+        c.depth += 1;
+        const bool continue_tree = (c.cont != 0) && no_u_traj;
+        if (c.depth < cfg.max_depth && continue_tree) {
+            begin_doubling(pb, cfg, c, v);
+            if (threadIdx.x == 0) ch.ctl[chain] = c;
+            return;
+        }
+
+        // ---- 5. transition finished -----------------------------------------------------------------
+        const double lar = log(c.e_sum / (double)c.lf_count);
+        const int k = c.k;
+        if (threadIdx.x == 0) {
+            const size_t o = (size_t)chain * cfg.total + k;
+            ch.d_step_size[o] = c.eps;
+            ch.d_lar[o] = lar;
+            ch.d_target[o] = c.cand_bfac * c.cand_L;
+            ch.d_energy[o] = c.cand_energy;
+            ch.d_beta[o] = c.beta_k;
+            ch.d_leapfrogs[o] = c.lf_count;
+            ch.d_depth[o] = c.depth;
+            ch.d_flags[o] = (c.not_div ? 0 : 1) | (continue_tree ? 2 : 0) | (c.is_accepted ? 4 : 0);
+        }
+        if (k >= cfg.burnin) {
+            double* out = ch.samples + ((size_t)chain * (cfg.total - cfg.burnin) + (k - cfg.burnin)) * pb.dimp;
+            for (int e = threadIdx.x; e < dim; e += blockDim.x) out[e] = v.candq[e];
+        }
+        if (c.is_accepted) c.beta_cache = c.beta_k;
+        dual_averaging(cfg, c, lar);
+        c.k = k + 1;
+    }
+    __syncthreads();
+    if (c.k >= stop_k) {
+        c.phase = PH_IDLE;
+        c.done_epoch = epoch;
+        if (threadIdx.x == 0) {
+            ch.ctl[chain] = c;
+            const int done = atomicAdd(&ch.gctl->done_chains, 1) + 1;
+            if (done >= ch.gctl->n_chains) ch.gctl->all_done = 1;
+        }
+        return;
+    }
+    begin_sample(pb, cfg, c, v, sh);
+    if (threadIdx.x == 0) ch.ctl[chain] = c;
+}
+
+__global__ void k_init_chains(DevChains ch, SamplerCfgDev cfg, const long long* chain_ids) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        ch.gctl->done_chains = 0;
+        ch.gctl->n_chains = ch.n_chains;
+        ch.gctl->all_done = 0;
+        ch.gctl->stop_k = 0;
+        ch.gctl->epoch = 0;
+    }
+    if (i >= ch.n_chains) return;
+    ChainCtl c{};
+    c.phase = PH_INIT;
+    c.chain_id = chain_ids ? chain_ids[i] : (long long)i;
+    c.da_step_size = cfg.step_size;
+    c.da_log_shrink = log(10.0 * cfg.step_size);
+    c.beta_cache = 1.0;
+    c.done_epoch = -1;
+    ch.ctl[i] = c;
+}
+
+}  // namespace
+
+int magi_launch_tail(magi_handle* h, int n_chains, hipStream_t s) {
+    hipLaunchKernelGGL(k_tail, dim3(n_chains), dim3(MAGI_TAIL_THREADS), 0, s, h->pb, h->ch, h->cfg);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("tail launch: ") + hipGetErrorString(e));
+    return MAGI_OK;
+}
+
+int magi_launch_init_chains(magi_handle* h, const long long* d_chain_ids, hipStream_t s) {
+    const int n = h->n_chains;
+    hipLaunchKernelGGL(k_init_chains, dim3((n + 63) / 64), dim3(64), 0, s, h->ch, h->cfg, d_chain_ids);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("init launch: ") + hipGetErrorString(e));
+    return MAGI_OK;
+}

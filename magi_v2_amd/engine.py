@@ -1,0 +1,277 @@
+"""ctypes binding of libmagi_hip.so (include/magi_hip.h) -- the only compute path of the package.
+
+There is deliberately no CPU fallback: if the shared library or a GPU is missing every entry point
+raises.  numpy arrays in, numpy arrays out; layouts follow the reference ([N, D] trajectories).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmagi_hip.so")
+
+DRIFT_IDS = {"seir3": 0, "seir4": 1, "sirw": 2}
+DRIFT_SHAPES = {"seir3": (3, 3), "seir4": (4, 3), "sirw": (4, 5)}   # name -> (D, P)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+
+
+class MagiHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmagi_hip error {code}: {msg}")
+        self.code = code
+
+
+class SamplerCfg(C.Structure):
+    """Mirror of ``magi_sampler_cfg``; defaults = the reference's (magi_v2.py:357-366)."""
+    _fields_ = [("num_results", C.c_int32), ("num_burnin_steps", C.c_int32), ("num_adaptation_steps", C.c_int32),
+                ("max_tree_depth", C.c_int32), ("mode", C.c_int32), ("hmc_leapfrogs", C.c_int32),
+                ("anneal", C.c_int32), ("stale_cache", C.c_int32), ("step_size", C.c_double),
+                ("target_accept_prob", C.c_double), ("max_energy_diff", C.c_double), ("min_temp", C.c_double)]
+
+
+_SYMBOLS = {
+    "magi_create": (C.c_void_p, [C.c_int]),
+    "magi_destroy": (None, [C.c_void_p]),
+    "magi_last_error": (C.c_char_p, [C.c_void_p]),
+    "magi_version": (C.c_char_p, []),
+    "magi_build_matrices": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, _dp, _dp, _dp]),
+    "magi_matern_blocks": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp]),
+    "magi_set_matrices": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]),
+    "magi_set_problem": (C.c_int, [C.c_void_p, _dp, _dp, _lp, _dp, C.c_int64, C.c_double, _dp, C.c_int, C.c_int]),
+    "magi_logpost_grad": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp]),
+    "magi_sampler_cfg_default": (None, [C.POINTER(SamplerCfg)]),
+    "magi_sampler_init": (C.c_int, [C.c_void_p, C.POINTER(SamplerCfg), C.c_int, _dp, _dp, _dp, C.c_uint64, _lp]),
+    "magi_sampler_run": (C.c_int, [C.c_void_p, C.c_int, _lp, _dp]),
+    "magi_sampler_steps_done": (C.c_int, [C.c_void_p, _lp]),
+    "magi_sampler_get_samples": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
+    "magi_sampler_get_diag": (C.c_int, [C.c_void_p, _dp, _dp, _ip, _ip, _ip, _ip, _ip, _dp, _dp, _dp]),
+    "magi_sampler_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp]),
+    "magi_sample": (C.c_int, [C.c_void_p, C.POINTER(SamplerCfg), C.c_int, _dp, _dp, _dp, C.c_uint64, _lp, _dp, _dp, _dp]),
+    "magi_time_gradient": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp]),
+    "magi_gradient_bytes": (C.c_int, [C.c_void_p, C.c_int, _dp]),
+}
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libmagi_hip.so and declare every symbol of include/magi_hip.h.  Raises if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError(f"{p} not found: build it with `python -m magi_v2_amd.build` (hipcc, gfx950); "
+                          "magi_v2_amd has no CPU fallback")
+    lib = C.CDLL(p)
+    for name, (res, args) in _SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SYMBOLS)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+@dataclass
+class SamplerDiag:
+    step_size: np.ndarray
+    log_accept_ratio: np.ndarray
+    leapfrogs_taken: np.ndarray
+    tree_depth: np.ndarray
+    has_divergence: np.ndarray
+    reach_max_depth: np.ndarray
+    is_accepted: np.ndarray
+    target_log_prob: np.ndarray
+    energy: np.ndarray
+    beta_temp: np.ndarray
+
+
+class MagiEngine:
+    """One handle = one GPU.  Not thread-safe; different engines may be used from different threads."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = load_library()
+        self._h = self._lib.magi_create(int(device_id))
+        if not self._h:
+            raise MagiHipError(-2, self._lib.magi_last_error(None).decode())
+        self.N = self.D = self.P = None
+        self.n_chains = 0
+        self._cfg = None
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.magi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MagiHipError(rc, self._lib.magi_last_error(self._h).decode())
+
+    @staticmethod
+    def version():
+        return load_library().magi_version().decode()
+
+    # -- matrices -------------------------------------------------------------------------------
+    def build_matrices(self, I, phi1s, phi2s, nu=2.01, bandsize=None, want_host=True):
+        """magi_v2.py:774-823 + :126-128 + :271-274 on the GPU for all components."""
+        I = _f64(np.asarray(I).reshape(-1))
+        phi1s, phi2s = _f64(phi1s), _f64(phi2s)
+        N, D = I.shape[0], phi1s.shape[0]
+        b = -1 if bandsize is None else int(bandsize)
+        outs = [np.empty((D, N, N)) for _ in range(3)] if want_host else [None, None, None]
+        self._check(self._lib.magi_build_matrices(self._h, _ptr(I), N, D, _ptr(phi1s), _ptr(phi2s), float(nu), b,
+                                                  *[_ptr(o) for o in outs]))
+        self.N, self.D = N, D
+        return tuple(outs) if want_host else None
+
+    def matern_blocks(self, I, phi1, phi2, nu=2.01):
+        I = _f64(np.asarray(I).reshape(-1))
+        N = I.shape[0]
+        outs = [np.empty((N, N)) for _ in range(3)]
+        self._check(self._lib.magi_matern_blocks(self._h, _ptr(I), N, float(phi1), float(phi2), float(nu),
+                                                 *[_ptr(o) for o in outs]))
+        return tuple(outs)
+
+    def set_matrices(self, C_inv, m, K_inv, bandsize=None):
+        C_inv = _f64(C_inv)
+        D, N, _ = C_inv.shape
+        m, K_inv = _f64(m, (D, N, N)), _f64(K_inv, (D, N, N))
+        b = -1 if bandsize is None else int(bandsize)
+        self._check(self._lib.magi_set_matrices(self._h, N, D, b, _ptr(C_inv), _ptr(m), _ptr(K_inv)))
+        self.N, self.D = N, D
+
+    # -- problem --------------------------------------------------------------------------------
+    def set_problem(self, mu, N_ds, obs_idx, y, beta, LB, drift: str):
+        D = self.D
+        P = DRIFT_SHAPES[drift][1]
+        mu, N_ds, LB = _f64(mu, (D,)), _f64(N_ds, (D,)), _f64(LB, (D,))
+        obs_idx = np.ascontiguousarray(obs_idx, dtype=np.int64)
+        y = _f64(y, obs_idx.shape)
+        self._check(self._lib.magi_set_problem(self._h, _ptr(mu), _ptr(N_ds), obs_idx.ctypes.data_as(_lp), _ptr(y),
+                                               obs_idx.shape[0], float(beta), _ptr(LB), DRIFT_IDS[drift], P))
+        self.P = P
+
+    def _states(self, X, sig_pre, th_pre):
+        X = _f64(X)
+        if X.ndim == 2:
+            X, sig_pre, th_pre = X[None], np.asarray(sig_pre)[None], np.asarray(th_pre)[None]
+        n = X.shape[0]
+        X = _f64(X, (n, self.N, self.D))
+        return n, X, _f64(sig_pre, (n, self.D)), _f64(th_pre, (n, self.P))
+
+    def logpost_grad(self, X, sig_pre, th_pre, beta_temp=1.0, want_terms=False):
+        """unnormalized_log_prob (magi_v2.py:308-348) + gradient for one state or a batch of states."""
+        single = np.asarray(X).ndim == 2
+        n, X, sp, tp = self._states(X, sig_pre, th_pre)
+        logp, gX = np.empty(n), np.empty((n, self.N, self.D))
+        gs, gt, terms = np.empty((n, self.D)), np.empty((n, self.P)), np.empty((n, 4))
+        self._check(self._lib.magi_logpost_grad(self._h, n, _ptr(X), _ptr(sp), _ptr(tp), float(beta_temp), _ptr(logp),
+                                                _ptr(gX), _ptr(gs), _ptr(gt), _ptr(terms)))
+        out = (logp[0], gX[0], gs[0], gt[0]) if single else (logp, gX, gs, gt)
+        if want_terms:
+            out = out + ((terms[0] if single else terms),)
+        return out
+
+    # -- sampler --------------------------------------------------------------------------------
+    def default_cfg(self, **kw) -> SamplerCfg:
+        cfg = SamplerCfg()
+        self._lib.magi_sampler_cfg_default(C.byref(cfg))
+        for k, v in kw.items():
+            if not hasattr(cfg, k):
+                raise TypeError(f"unknown sampler option {k}")
+            setattr(cfg, k, v)
+        return cfg
+
+    def sampler_init(self, cfg: SamplerCfg, X0, sig_pre0, th_pre0, seed: int, chain_ids: Optional[Sequence[int]] = None):
+        n, X, sp, tp = self._states(X0, sig_pre0, th_pre0)
+        ids = None
+        if chain_ids is not None:
+            ids = np.ascontiguousarray(chain_ids, dtype=np.int64)
+            if ids.shape != (n,):
+                raise ValueError("chain_ids must have one entry per chain")
+        self._check(self._lib.magi_sampler_init(self._h, C.byref(cfg), n, _ptr(X), _ptr(sp), _ptr(tp),
+                                                C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+                                                None if ids is None else ids.ctypes.data_as(_lp)))
+        self.n_chains = n
+        self._cfg = cfg
+
+    def sampler_run(self, n_steps: int):
+        """Advance all chains by n_steps transitions; returns (leapfrogs taken, device ms)."""
+        lf = C.c_int64(0)
+        ms = C.c_double(0.0)
+        self._check(self._lib.magi_sampler_run(self._h, int(n_steps), C.byref(lf), C.byref(ms)))
+        return lf.value, ms.value
+
+    def sampler_steps_done(self):
+        out = np.zeros(self.n_chains, dtype=np.int64)
+        self._check(self._lib.magi_sampler_steps_done(self._h, out.ctypes.data_as(_lp)))
+        return out
+
+    def sampler_samples(self):
+        n, R = self.n_chains, self._cfg.num_results
+        X = np.empty((n, R, self.N, self.D))
+        sp, tp = np.empty((n, R, self.D)), np.empty((n, R, self.P))
+        self._check(self._lib.magi_sampler_get_samples(self._h, _ptr(X), _ptr(sp), _ptr(tp)))
+        return X, sp, tp
+
+    def sampler_diag(self) -> SamplerDiag:
+        n, T = self.n_chains, self._cfg.num_results + self._cfg.num_burnin_steps
+        f = lambda: np.zeros((n, T))
+        i = lambda: np.zeros((n, T), dtype=np.int32)
+        d = SamplerDiag(f(), f(), i(), i(), i(), i(), i(), f(), f(), f())
+        ip = lambda a: a.ctypes.data_as(_ip)
+        self._check(self._lib.magi_sampler_get_diag(self._h, _ptr(d.step_size), _ptr(d.log_accept_ratio),
+                                                    ip(d.leapfrogs_taken), ip(d.tree_depth), ip(d.has_divergence),
+                                                    ip(d.reach_max_depth), ip(d.is_accepted), _ptr(d.target_log_prob),
+                                                    _ptr(d.energy), _ptr(d.beta_temp)))
+        return d
+
+    def sampler_state(self):
+        n = self.n_chains
+        X, sp, tp = np.empty((n, self.N, self.D)), np.empty((n, self.D)), np.empty((n, self.P))
+        ss, bc = np.empty(n), np.empty(n)
+        self._check(self._lib.magi_sampler_get_state(self._h, _ptr(X), _ptr(sp), _ptr(tp), _ptr(ss), _ptr(bc)))
+        return X, sp, tp, ss, bc
+
+    # -- instrumentation ------------------------------------------------------------------------
+    def time_gradient(self, n_chains=1, reps=50):
+        total = C.c_double(0.0)
+        ph = np.zeros(4)
+        self._check(self._lib.magi_time_gradient(self._h, int(n_chains), int(reps), C.byref(total), _ptr(ph)))
+        return total.value, ph
+
+    def gradient_bytes(self, n_chains=1):
+        b = np.zeros(4)
+        self._check(self._lib.magi_gradient_bytes(self._h, int(n_chains), _ptr(b)))
+        return b

@@ -1,0 +1,111 @@
+"""GPU parity of the device-resident NUTS state machine against the oracle's restatement of
+TFP's NUTS + dual averaging + LogAnnealedNUTS (magi_v2.py:357-396, 833-889) with the same
+Philox streams.  Integer diagnostics (tree depth, leapfrog counts, flags) must agree exactly;
+states agree to 1e-8 relative over the first transitions (the two sides differ only in fp64
+summation order and libm last-bit rounding, which the leapfrog dynamics amplify slowly).
+Sampler parity against TFP itself is UNPINNED (see oracle/magi_oracle.py)."""
+import numpy as np
+import pytest
+
+from oracle import magi_oracle as orc
+from tests.util import engine_for, load_g4, problem_from_g4
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_both(tag, band, burnin, results, seed, chain_ids=(0,), stale=1, anneal=1, theta0=None):
+    g = load_g4(tag)
+    pr = problem_from_g4(g, band)
+    pr_dense = problem_from_g4(g, None)
+    eng = engine_for(pr_dense, band)
+    P = pr.P
+    theta0 = np.ones(P) if theta0 is None else theta0
+    X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], theta0, pr.LB)
+    n = len(chain_ids)
+    cfg = eng.default_cfg(num_results=results, num_burnin_steps=burnin, stale_cache=stale, anneal=anneal)
+    eng.sampler_init(cfg, np.repeat(X0[None], n, 0), np.repeat(s0[None], n, 0), np.repeat(t0[None], n, 0), seed=seed,
+                     chain_ids=list(chain_ids))
+    lf, ms = eng.sampler_run(burnin + results)
+    Xs, sp, tp = eng.sampler_samples()
+    diag = eng.sampler_diag()
+    oracle = []
+    for cid in chain_ids:
+        trace = []
+        out = orc.sample_chain(pr, g["Xhat_init"], g["sigma_sqs_init"], theta0, results, burnin, seed=seed, chain=cid,
+                               stale_cache=bool(stale), anneal=bool(anneal), trace=trace)
+        oracle.append((out, trace))
+    eng.close()
+    return (Xs, sp, tp, diag, lf), oracle
+
+
+@pytest.mark.parametrize("tag,band,stale", [("seir3_N161", 80, 1), ("seir4_N81", None, 1), ("sirw_N41", 5, 0)])
+def test_chain_matches_oracle_draw_for_draw(tag, band, stale):
+    burnin, results = 8, 4
+    (Xs, sp, tp, diag, lf), oracle = _run_both(tag, band, burnin, results, seed=1234, stale=stale)
+    (oX, osp, otp, info, da), trace = oracle[0]
+    depth = np.array([r.depth for _, r, _ in trace])
+    leap = np.array([r.leapfrogs for _, r, _ in trace])
+    np.testing.assert_array_equal(diag.tree_depth[0], depth)
+    np.testing.assert_array_equal(diag.leapfrogs_taken[0], leap)
+    np.testing.assert_array_equal(diag.has_divergence[0], [int(r.has_divergence) for _, r, _ in trace])
+    np.testing.assert_array_equal(diag.is_accepted[0], [int(r.is_accepted) for _, r, _ in trace])
+    assert lf == leap.sum()
+    ss = np.array([s for _, _, s in trace])
+    np.testing.assert_allclose(diag.step_size[0], ss, rtol=1e-9)
+    lar = np.array([r.log_accept_ratio for _, r, _ in trace])
+    fin = np.isfinite(lar)
+    np.testing.assert_array_equal(np.isfinite(diag.log_accept_ratio[0]), fin)
+    np.testing.assert_allclose(diag.log_accept_ratio[0][fin], lar[fin], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(diag.target_log_prob[0], [r.target_log_prob for _, r, _ in trace], rtol=1e-8)
+    np.testing.assert_allclose(diag.beta_temp[0], [orc.temperature(k) for k in range(burnin + results)], rtol=1e-15)
+    np.testing.assert_allclose(Xs[0], oX, rtol=0, atol=1e-8 * np.abs(oX).max())
+    np.testing.assert_allclose(sp[0], osp, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(tp[0], otp, rtol=1e-7, atol=1e-9)
+
+
+def test_chains_are_independent_of_batching_and_ids():
+    """Philox streams are keyed by the global chain id: a chain gives the same samples whether it
+    runs alone, inside a batch, or on another GPU."""
+    (Xs, sp, tp, diag, _), oracle = _run_both("sirw_N41", None, 4, 3, seed=99, chain_ids=(5, 2, 11))
+    for i in range(3):
+        (oX, osp, otp, info, da), trace = oracle[i]
+        np.testing.assert_array_equal(diag.leapfrogs_taken[i], [r.leapfrogs for _, r, _ in trace])
+        np.testing.assert_allclose(tp[i], otp, rtol=1e-7, atol=1e-9)
+    assert not np.allclose(tp[0], tp[1])
+
+
+def test_pause_resume_equals_single_run():
+    g = load_g4("sirw_N41")
+    pr = problem_from_g4(g, None)
+    outs = []
+    for chunks in ([10], [3, 1, 6]):
+        eng = engine_for(pr, None)
+        X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], np.ones(pr.P), pr.LB)
+        cfg = eng.default_cfg(num_results=4, num_burnin_steps=6)
+        eng.sampler_init(cfg, X0, s0, t0, seed=5)
+        for c in chunks:
+            eng.sampler_run(c)
+        assert list(eng.sampler_steps_done()) == [10]
+        outs.append(eng.sampler_samples())
+        eng.close()
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_recovers_seir_parameters_statistically():
+    """Vignette configuration (SEIR-3, N=161, b=80; vignette.ipynb cells 5-8) at reduced length:
+    posterior-mean theta must land near the truth (6, 0.6, 1.8); the reference's own 1000+1000 run
+    printed (5.831, 0.565, 1.77) (vignette.ipynb cell 11) -- stochastic, unseeded, so only a loose
+    statistical check is possible."""
+    g = load_g4("seir3_N161")
+    pr = problem_from_g4(g, None)
+    eng = engine_for(pr, 80)
+    X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], np.ones(3), pr.LB)
+    cfg = eng.default_cfg(num_results=150, num_burnin_steps=150)
+    eng.sampler_init(cfg, np.repeat(X0[None], 4, 0), np.repeat(s0[None], 4, 0), np.repeat(t0[None], 4, 0), seed=2024)
+    eng.sampler_run(300)
+    Xs, sp, tp = eng.sampler_samples()
+    _, th = orc.transform_samples(sp, tp, pr.LB)
+    mean = th.reshape(-1, 3).mean(axis=0)
+    eng.close()
+    assert abs(mean[0] - 6.0) < 1.5 and abs(mean[1] - 0.6) < 0.2 and abs(mean[2] - 1.8) < 0.5, mean
