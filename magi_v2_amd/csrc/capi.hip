@@ -1,6 +1,7 @@
 // extern "C" entry points of libmagi_hip.so (see include/magi_hip.h for the contract).
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 
 #include "magi_internal.h"
@@ -27,7 +28,7 @@ void free_matrices(magi_handle* h) {
 
 void free_chains(magi_handle* h) {
     DevChains& c = h->ch;
-    free_dev(c.vec); free_dev(c.ctl); free_dev(c.gctl); free_dev(c.samples);
+    free_dev(c.vec); free_dev(c.ctl); free_dev(c.par); free_dev(c.gctl); free_dev(c.samples);
     free_dev(c.d_step_size); free_dev(c.d_lar); free_dev(c.d_target); free_dev(c.d_energy); free_dev(c.d_beta);
     free_dev(c.d_leapfrogs); free_dev(c.d_depth); free_dev(c.d_flags);
     free_dev(h->d_chain_ids); free_dev(h->d_fin);
@@ -101,6 +102,8 @@ int magi_ensure_chains(magi_handle* h, int n) {
         MAGI_HIP_CHECK(h, hipMemset(h->ch.vec, 0, vbytes));
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.ctl, sizeof(ChainCtl) * n));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.ctl, 0, sizeof(ChainCtl) * n));
+        MAGI_HIP_CHECK(h, hipMalloc(&h->ch.par, sizeof(double) * PAR_COUNT * n));
+        MAGI_HIP_CHECK(h, hipMemset(h->ch.par, 0, sizeof(double) * PAR_COUNT * n));
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.gctl, sizeof(GlobalCtl)));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.gctl, 0, sizeof(GlobalCtl)));
         MAGI_HIP_CHECK(h, hipMalloc(&h->d_chain_ids, sizeof(long long) * n));
@@ -257,6 +260,7 @@ int magi_logpost_grad(magi_handle* h, int n_chains, const double* X, const doubl
     const DevProblem& pb = h->pb;
     if ((rc = upload_states(h, n_chains, X, sig_pre, th_pre))) return rc;
     MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.gctl, 0, sizeof(GlobalCtl), h->stream));
+    if ((rc = magi_launch_prepare(h, n_chains, h->stream))) return rc;
     if ((rc = magi_launch_gradient(h, n_chains, h->stream))) return rc;
     if ((rc = magi_launch_finalize(h, n_chains, h->d_fin, h->stream))) return rc;
     MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
@@ -351,6 +355,7 @@ int magi_sampler_init(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains,
     MAGI_HIP_CHECK(h, hipMemcpy(h->d_chain_ids, ids.data(), sizeof(long long) * n_chains, hipMemcpyHostToDevice));
     if ((rc = magi_launch_init_chains(h, h->d_chain_ids, h->stream))) return rc;
     // bootstrap_results: one gradient at the initial state (the tail stores it as the proposal)
+    if ((rc = magi_launch_prepare(h, n_chains, h->stream))) return rc;
     if ((rc = magi_launch_gradient(h, n_chains, h->stream))) return rc;
     if ((rc = magi_launch_tail(h, n_chains, h->stream))) return rc;
     MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
@@ -375,7 +380,10 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
     if (n_steps <= 0) return magi_fail(h, MAGI_E_BADARG, "n_steps must be positive");
     (void)hipSetDevice(h->device);
     int rc;
-    if (!h->graph_valid && (rc = build_graph(h))) return rc;
+    // MAGI_NO_GRAPH=1: launch the leapfrog slots directly (debugging / rocprofv3 kernel traces of
+    // long runs: the profiler's graph-node bookkeeping does not survive ~10^5 replayed nodes)
+    const bool use_graph = getenv("MAGI_NO_GRAPH") == nullptr;
+    if (use_graph && !h->graph_valid && (rc = build_graph(h))) return rc;
 
     std::vector<ChainCtl> ctl(h->n_chains);
     MAGI_HIP_CHECK(h, hipMemcpy(ctl.data(), h->ch.ctl, sizeof(ChainCtl) * h->n_chains, hipMemcpyDeviceToHost));
@@ -401,7 +409,14 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
     while (!done) {
         while (issued - retired < depth && issued < max_graphs) {
             const int slot = (int)(issued % 4);
-            MAGI_HIP_CHECK(h, hipGraphLaunch(h->graph_exec, h->stream));
+            if (use_graph) {
+                MAGI_HIP_CHECK(h, hipGraphLaunch(h->graph_exec, h->stream));
+            } else {
+                for (int sl = 0; sl < kGraphSlots; ++sl) {
+                    if ((rc = magi_launch_gradient(h, h->n_chains, h->stream))) return rc;
+                    if ((rc = magi_launch_tail(h, h->n_chains, h->stream))) return rc;
+                }
+            }
             MAGI_HIP_CHECK(h, hipMemcpyAsync(&h->h_gctl[slot], h->ch.gctl, sizeof(GlobalCtl), hipMemcpyDeviceToHost, h->stream));
             MAGI_HIP_CHECK(h, hipEventRecord(h->ev[slot], h->stream));
             ++issued;
@@ -521,6 +536,7 @@ int magi_time_gradient(magi_handle* h, int n_chains, int reps, double* total_ms_
     int rc = magi_ensure_chains(h, n_chains);
     if (rc) return rc;
     MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.gctl, 0, sizeof(GlobalCtl), h->stream));
+    if ((rc = magi_launch_prepare(h, n_chains, h->stream))) return rc;
     float ms = 0.f;
     // warm
     for (int i = 0; i < 3; ++i) {

@@ -26,7 +26,7 @@ __device__ inline double load_src(const DevProblem& pb, const double* vb, int d,
 
 // Row epilogue shared by the dense and banded kernels: v0 / v1 are the finished row sums.
 template <int PHASE>
-__device__ inline void row_epilogue(const DevProblem& pb, double* vb, int d, int row, double v0, double v1) {
+__device__ inline void row_epilogue(const DevProblem& pb, double* vb, const double* par, int d, int row, double v0, double v1) {
     const int N = pb.N, dimp = pb.dimp;
     const size_t e = (size_t)d * N + row;
     if (PHASE == 2) {
@@ -38,7 +38,7 @@ __device__ inline void row_epilogue(const DevProblem& pb, double* vb, int d, int
 #pragma unroll
     for (int dd = 0; dd < MAGI_MAX_D; ++dd) xg[dd] = (dd < pb.D) ? q[dd * N + row] : 0.0;
 #pragma unroll
-    for (int p = 0; p < MAGI_MAX_P; ++p) th[p] = (p < pb.P) ? softplus_ref(q[pb.ND + pb.D + p]) : 0.0;
+    for (int p = 0; p < MAGI_MAX_P; ++p) th[p] = (p < pb.P) ? par[PAR_TH + p] : 0.0;
     if (PHASE == 1) {
         vb[(size_t)V_CX * dimp + e] = v0;
         vb[(size_t)V_R * dimp + e] = drift_f(pb.drift, d, xg, th) - v1;
@@ -52,8 +52,7 @@ __device__ inline void row_epilogue(const DevProblem& pb, double* vb, int d, int
         const double y = pb.yobs[e];
         double d4 = 0.0;
         if (!isnan(y)) {
-            const double sig2 = softplus_ref(q[pb.ND + d]) + pb.LB[d];
-            d4 = 2.0 * (q[e] - y) / sig2;
+            d4 = 2.0 * (q[e] - y) / par[PAR_SIG2 + d];
         }
         vb[(size_t)V_G * dimp + e] = -0.5 * (pb.beta_inv * d12 + d4);
     }
@@ -135,7 +134,8 @@ __global__ __launch_bounds__(256) void k_matvec_dense(DevProblem pb, DevChains c
     if (lane < R * NC) {
         const int r = lane / NC, c = lane - r * NC;
         const int row = row0 + r, cc = c0 + c;
-        if (row < N && cc < ch.n_chains) row_epilogue<PHASE>(pb, ch.vec + vec_off(pb, cc, 0), d, row, v0, v1);
+        if (row < N && cc < ch.n_chains)
+            row_epilogue<PHASE>(pb, ch.vec + vec_off(pb, cc, 0), ch.par + (size_t)cc * PAR_COUNT, d, row, v0, v1);
     }
 }
 
@@ -194,16 +194,18 @@ __global__ __launch_bounds__(256) void k_matvec_band(DevProblem pb, DevChains ch
     if (lane < R * NC) {
         const int r = lane / NC, c = lane - r * NC;
         const int row = rb + wave * R + r, cc = c0 + c;
-        if (row < N && cc < ch.n_chains) row_epilogue<PHASE>(pb, ch.vec + vec_off(pb, cc, 0), d, row, v0, v1);
+        if (row < N && cc < ch.n_chains)
+            row_epilogue<PHASE>(pb, ch.vec + vec_off(pb, cc, 0), ch.par + (size_t)cc * PAR_COUNT, d, row, v0, v1);
     }
 }
 
 // ---- reduce: one 1024-thread workgroup per chain; out[chain][8] = L, t1, t2, t3, t4 ------------
 __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_finalize(DevProblem pb, DevChains ch, double* out) {
-    __shared__ double sh[(2 + MAGI_MAX_D + MAGI_MAX_P) * 16];
+    __shared__ double sh[(3 + MAGI_MAX_D + MAGI_MAX_P) * 16];
+    __shared__ double shs[8];
     const int c = blockIdx.x;
     double* vb = ch.vec + vec_off(pb, c, 0);
-    FinalizeOut fo = finalize_gradient(pb, vb, sh);
+    FinalizeOut fo = finalize_gradient(pb, vb, ch.par + (size_t)c * PAR_COUNT, sh, shs);
     if (threadIdx.x == 0 && out) {
         out[c * 8 + 0] = fo.L;
         out[c * 8 + 1] = fo.t1;
@@ -211,6 +213,13 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_finalize(DevProblem pb, D
         out[c * 8 + 3] = fo.t3;
         out[c * 8 + 4] = fo.t4;
     }
+}
+
+// transformed parameters of the states in V_Q (API path; the sampler's tail does this itself)
+__global__ void k_prepare(DevProblem pb, DevChains ch) {
+    const int c = blockIdx.x, j = threadIdx.x;
+    if (j < pb.D + pb.P)
+        compute_par_entry(pb, j, ch.vec[vec_off(pb, c, V_Q) + pb.ND + j], ch.par + (size_t)c * PAR_COUNT);
 }
 
 template <int PHASE, int NC>
@@ -256,6 +265,13 @@ int magi_launch_gradient(magi_handle* h, int n_chains, hipStream_t s) {
     if ((rc = launch_phase<1>(h, n_chains, s))) return rc;
     if ((rc = launch_phase<2>(h, n_chains, s))) return rc;
     return launch_phase<3>(h, n_chains, s);
+}
+
+int magi_launch_prepare(magi_handle* h, int n_chains, hipStream_t s) {
+    hipLaunchKernelGGL(k_prepare, dim3(n_chains), dim3(64), 0, s, h->pb, h->ch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("prepare launch: ") + hipGetErrorString(e));
+    return MAGI_OK;
 }
 
 int magi_launch_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s) {

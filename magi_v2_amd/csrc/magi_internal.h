@@ -110,6 +110,7 @@ struct GlobalCtl {
 struct DevChains {
     double* vec;          // [n_chains][V_COUNT][dimp]
     ChainCtl* ctl;        // [n_chains]
+    double* par;          // [n_chains][PAR_COUNT] transformed parameters of the state in V_Q
     GlobalCtl* gctl;
     int n_chains;
     // outputs
@@ -187,6 +188,32 @@ __device__ inline double logaddexp(double a, double b) {
 
 __device__ inline double temperature(int step, double min_temp) {   // magi_v2.py:833-835
     return fmax(1.0 / log((double)step + 2.0), min_temp);
+}
+
+// ------------------------------------------------------------------------------------------
+// Transformed parameters of a state (magi_v2.py:318-323), computed ONCE per state by whoever
+// writes V_Q (fp64 exp/log are ~100-instruction sequences: keeping them out of the per-row
+// epilogues and out of the 1024-thread reduce is worth tens of microseconds per gradient).
+// ------------------------------------------------------------------------------------------
+enum ParOff { PAR_TH = 0, PAR_SGT = 8, PAR_LJT = 16, PAR_SIG2 = 24, PAR_SGS = 28, PAR_LJS = 32, PAR_LOG2PIS = 36, PAR_COUNT = 64 };
+
+// entry j of the parameter block: j < D -> sigma_pre[j], else theta_pre[j - D]
+__device__ inline void compute_par_entry(const DevProblem& pb, int j, double pre, double* par) {
+    const double sp = softplus_ref(pre);
+    const double sg = sigmoid(pre);
+    if (j < pb.D) {
+        const double lb = (j == 0) ? pb.LB[0] : (j == 1) ? pb.LB[1] : (j == 2) ? pb.LB[2] : pb.LB[3];
+        const double s2 = sp + lb;
+        par[PAR_SIG2 + j] = s2;
+        par[PAR_SGS + j] = sg;
+        par[PAR_LJS + j] = pre - sp;
+        par[PAR_LOG2PIS + j] = log(2.0 * 3.141592653589793 * s2);
+    } else {
+        const int p = j - pb.D;
+        par[PAR_TH + p] = sp;
+        par[PAR_SGT + p] = sg;
+        par[PAR_LJT + p] = pre - sp;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -282,27 +309,66 @@ __device__ __forceinline__ void drift_tt_g_acc(int drift, const double (&x)[MAGI
 // ------------------------------------------------------------------------------------------
 // reductions: 64-lane butterfly, then a fixed-order sum over the block's waves (deterministic)
 // ------------------------------------------------------------------------------------------
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+// All cross-lane traffic stays on the VALU (DPP row operations + gfx950's v_permlane{16,32}_swap);
+// the ds_bpermute path that __shfl_xor lowers to costs an LDS round trip per 32-bit half per step.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// butterfly inside each row of 16 lanes: every lane ends with its row's sum
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    v += dpp_f64<0x140>(v);   // row_mirror
     return v;
 }
 
+__device__ __forceinline__ double wave_sum(double v) {
+    v = row16_sum(v);
+    {   // rows 0<->1, 2<->3
+        unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    {   // lower 32 <-> upper 32
+        unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    return v;
+}
+
+// Block-wide sums of K values; every thread returns with all K totals.  sh: (K + 1) * 16 doubles.
+// Stage 1: per-wave butterflies, one partial per wave.  Stage 2: wave 0 adds the <= 16 partials of
+// each value with a row butterfly and publishes K totals (fixed order -> deterministic).
 template <int K>
-__device__ inline void block_sum(double (&v)[K], double* sh /* [K][16] */) {
+__device__ inline void block_sum(double (&v)[K], double* sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        double s = wave_sum(v[k]);
+        const double s = wave_sum(v[k]);
         if (lane == 0) sh[k * 16 + wave] = s;
     }
     __syncthreads();
+    if (wave == 0) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        double s = 0.0;
-        for (int w = 0; w < nw; ++w) s += sh[k * 16 + w];
-        v[k] = s;
+        for (int k = 0; k < K; ++k) {
+            double x = (lane < nw) ? sh[k * 16 + (lane & 15)] : 0.0;
+            if (lane >= 16) x = 0.0;
+            x = row16_sum(x);
+            if (lane == 0) sh[K * 16 + k] = x;
+        }
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = sh[K * 16 + k];
     __syncthreads();
 }
 
@@ -313,7 +379,17 @@ __device__ inline void block_sum(double (&v)[K], double* sh /* [K][16] */) {
 // ------------------------------------------------------------------------------------------
 struct FinalizeOut { double L, t1, t2, t3, t4; };
 
-__device__ inline FinalizeOut finalize_gradient(const DevProblem& pb, double* vb, double* sh) {
+template <int NSEL>
+__device__ __forceinline__ double select_lane(const double (&a)[NSEL], int base, int n, int j) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < NSEL; ++k)
+        if (k >= base && k < base + n && j == k - base) v = a[k];
+    return v;
+}
+
+// sh: [(2 + MAX_D + MAX_P) * 16] doubles, shs: [8] doubles of LDS scratch
+__device__ inline FinalizeOut finalize_gradient(const DevProblem& pb, double* vb, const double* par, double* sh, double* shs) {
     const int N = pb.N, D = pb.D, P = pb.P, ND = pb.ND, dimp = pb.dimp;
     const double* q = vb + (size_t)V_Q * dimp;
     const double* Cx = vb + (size_t)V_CX * dimp;
@@ -321,14 +397,9 @@ __device__ inline FinalizeOut finalize_gradient(const DevProblem& pb, double* vb
     const double* Kr = vb + (size_t)V_KR * dimp;
     double* g = vb + (size_t)V_G * dimp;
 
-    double th[MAGI_MAX_P], tpre[MAGI_MAX_P], spre[MAGI_MAX_D];
+    double th[MAGI_MAX_P];
 #pragma unroll
-    for (int p = 0; p < MAGI_MAX_P; ++p) {
-        tpre[p] = (p < P) ? q[ND + D + p] : 0.0;
-        th[p] = (p < P) ? softplus_ref(tpre[p]) : 0.0;
-    }
-#pragma unroll
-    for (int d = 0; d < MAGI_MAX_D; ++d) spre[d] = (d < D) ? q[ND + d] : 0.0;
+    for (int p = 0; p < MAGI_MAX_P; ++p) th[p] = (p < P) ? par[PAR_TH + p] : 0.0;
 
     constexpr int K = 2 + MAGI_MAX_D + MAGI_MAX_P;
     double t1s = 0.0, t2s = 0.0, ss[MAGI_MAX_D], tp[MAGI_MAX_P];
@@ -364,35 +435,42 @@ __device__ inline FinalizeOut finalize_gradient(const DevProblem& pb, double* vb
     for (int p = 0; p < MAGI_MAX_P; ++p) red[2 + MAGI_MAX_D + p] = tp[p];
     block_sum<K>(red, sh);
 
+    // scalar part: one wave, lane j <-> parameter j (no transcendental left: see compute_par_entry)
+    if (threadIdx.x < 64) {
+        const int j = threadIdx.x;
+        double t3 = 0.0, t4 = 0.0, lj = 0.0;
+        if (j < D) {
+            const double s2 = par[PAR_SIG2 + j], sg = par[PAR_SGS + j];
+            const double ssd = select_lane<K>(red, 2, MAGI_MAX_D, j);
+            const double nds = (j == 0) ? pb.N_ds[0] : (j == 1) ? pb.N_ds[1] : (j == 2) ? pb.N_ds[2] : pb.N_ds[3];
+            t3 = nds * par[PAR_LOG2PIS + j];
+            t4 = ssd * (1.0 / s2);
+            lj = par[PAR_LJS + j];
+            const double dsig = nds / s2 - ssd / (s2 * s2);
+            g[ND + j] = -0.5 * dsig * sg + (1.0 - sg);
+        } else if (j < D + P) {
+            const int p = j - D;
+            const double sg = par[PAR_SGT + p];
+            const double tpp = select_lane<K>(red, 2 + MAGI_MAX_D, MAGI_MAX_P, p);
+            lj = par[PAR_LJT + p];
+            g[ND + D + p] = -0.5 * pb.beta_inv * tpp * sg + (1.0 - sg);
+        }
+        t3 = wave_sum(t3);
+        t4 = wave_sum(t4);
+        lj = wave_sum(lj);
+        if (j == 0) {
+            shs[0] = -0.5 * ((pb.beta_inv * (red[0] + red[1])) + (t3 + t4)) + lj;
+            shs[1] = t3;
+            shs[2] = t4;
+        }
+    }
+    __syncthreads();   // V_G and shs complete for the whole block
     FinalizeOut o;
     o.t1 = red[0];
     o.t2 = red[1];
-    double t3 = 0.0, t4 = 0.0, ljs = 0.0, ljt = 0.0;
-#pragma unroll
-    for (int d = 0; d < MAGI_MAX_D; ++d) {
-        if (d < D) {
-            const double sp = softplus_ref(spre[d]);
-            const double s2 = sp + pb.LB[d];
-            t3 += pb.N_ds[d] * log(2.0 * 3.141592653589793 * s2);
-            t4 += red[2 + d] * (1.0 / s2);
-            ljs += spre[d] - sp;
-            const double sg = sigmoid(spre[d]);
-            const double dsig = pb.N_ds[d] / s2 - red[2 + d] / (s2 * s2);
-            if (threadIdx.x == 0) g[ND + d] = -0.5 * dsig * sg + (1.0 - sg);
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < MAGI_MAX_P; ++p) {
-        if (p < P) {
-            ljt += tpre[p] - softplus_ref(tpre[p]);
-            const double sg = sigmoid(tpre[p]);
-            if (threadIdx.x == 0) g[ND + D + p] = -0.5 * pb.beta_inv * red[2 + MAGI_MAX_D + p] * sg + (1.0 - sg);
-        }
-    }
-    o.t3 = t3;
-    o.t4 = t4;
-    o.L = -0.5 * ((pb.beta_inv * (o.t1 + o.t2)) + (t3 + t4)) + ljs + ljt;
-    __syncthreads();   // V_G complete for the whole block
+    o.L = shs[0];
+    o.t3 = shs[1];
+    o.t4 = shs[2];
     return o;
 }
 
@@ -450,6 +528,7 @@ int magi_fail(magi_handle* h, int code, const std::string& msg);
 int magi_launch_gradient(magi_handle* h, int n_chains, hipStream_t s);        // phases 1-3
 int magi_launch_phase(magi_handle* h, int phase, int n_chains, hipStream_t s);
 int magi_launch_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s);
+int magi_launch_prepare(magi_handle* h, int n_chains, hipStream_t s);   // fills par from V_Q
 int magi_launch_tail(magi_handle* h, int n_chains, hipStream_t s);
 int magi_launch_init_chains(magi_handle* h, const long long* d_chain_ids, hipStream_t s);
 int magi_ensure_chains(magi_handle* h, int n_chains);

@@ -35,9 +35,16 @@ __device__ inline TailVecs tail_vecs(const DevProblem& pb, double* vb) {
     return v;
 }
 
+// Scalar transcendental math is evaluated by ONE thread and broadcast through LDS: an fp64
+// exp/log is a ~100-instruction sequence, and 16 waves evaluating it redundantly cost tens of
+// microseconds per leapfrog (measured: 44 us tail -> see profiles/).
+struct Bcast {
+    double* s;   // LDS, >= 16 doubles
+};
+
 // Start a doubling from the end selected by the direction bit and take the first half/full step
 // (leapfrog with identity mass: p_half = p + eps/2 * grad ; q' = q + eps * p_half).
-__device__ inline void begin_doubling(const DevProblem& pb, const SamplerCfgDev& cfg, ChainCtl& c, const TailVecs& v) {
+__device__ inline void begin_doubling(const DevProblem& pb, const SamplerCfgDev& cfg, ChainCtl& c, const TailVecs& v, double* par) {
     const int dim = pb.dim;
     Philox4 r = philox4x32_10((unsigned)c.depth, (unsigned)c.k, (unsigned)c.chain_id, STREAM_DIRECTION, cfg.seed);
     const bool fwd = (r.x & 1u) != 0;
@@ -51,8 +58,10 @@ __device__ inline void begin_doubling(const DevProblem& pb, const SamplerCfgDev&
     for (int e = threadIdx.x; e < dim; e += blockDim.x) {
         const double ph = pe[e] + hs * ge[e];
         v.p[e] = ph;
-        v.q[e] = qe[e] + eps * ph;
+        const double qn = qe[e] + eps * ph;
+        v.q[e] = qn;
         v.rhosub[e] = 0.0;
+        if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par);
     }
     c.nsteps = 1 << c.depth;
     c.it = 0;
@@ -65,11 +74,11 @@ __device__ inline void begin_doubling(const DevProblem& pb, const SamplerCfgDev&
 }
 
 // Start transition k: temperature, momentum draw, both ends = current proposal, first doubling.
-__device__ inline void begin_sample(const DevProblem& pb, const SamplerCfgDev& cfg, ChainCtl& c, const TailVecs& v, double* sh) {
+__device__ inline void begin_sample(const DevProblem& pb, const SamplerCfgDev& cfg, ChainCtl& c, const TailVecs& v, double* par,
+                                    double* sh, double* shs) {
     const int dim = pb.dim;
-    c.beta_k = cfg.anneal ? temperature(c.k, cfg.min_temp) : 1.0;
-    const double bc = cfg.stale ? c.beta_cache : c.beta_k;
-    c.eps = c.da_step_size;
+    __syncthreads();
+    if (threadIdx.x == 0) shs[4] = cfg.anneal ? temperature(c.k, cfg.min_temp) : 1.0;
     double pp[1] = {0.0};
     for (int e = threadIdx.x; e < dim; e += blockDim.x) {
         const double z = rng_normal_elem((unsigned)e, (unsigned)c.k, (unsigned)c.chain_id, cfg.seed);
@@ -79,7 +88,10 @@ __device__ inline void begin_sample(const DevProblem& pb, const SamplerCfgDev& c
         v.qL[e] = qq; v.qR[e] = qq;
         v.gL[e] = gg; v.gR[e] = gg;
     }
-    block_sum<1>(pp, sh);
+    block_sum<1>(pp, sh);              // (its barriers also publish shs[4])
+    c.beta_k = shs[4];
+    const double bc = cfg.stale ? c.beta_cache : c.beta_k;
+    c.eps = c.da_step_size;
     c.init_energy = bc * c.cand_L - 0.5 * pp[0];
     c.LL = c.LR = c.cand_L;
     c.bfacL = c.bfacR = bc;
@@ -92,11 +104,13 @@ __device__ inline void begin_sample(const DevProblem& pb, const SamplerCfgDev& c
     c.is_accepted = 0;
     c.depth = 0;
     c.leaf_ctr = 0;
-    begin_doubling(pb, cfg, c, v);
+    begin_doubling(pb, cfg, c, v, par);
 }
 
-// DualAveragingStepSizeAdaptation.one_step after the inner NUTS step (oracle: dual_averaging_update)
-__device__ inline void dual_averaging(const SamplerCfgDev& cfg, ChainCtl& c, double log_accept_ratio) {
+// DualAveragingStepSizeAdaptation.one_step after the inner NUTS step (oracle: dual_averaging_update).
+// Evaluated by one thread; results returned through out[0..3].
+__device__ inline void dual_averaging_eval(const SamplerCfgDev& cfg, const ChainCtl& c, double e_sum, int lf_count, double* out) {
+    const double log_accept_ratio = log(e_sum / (double)lf_count);
     double lap = isfinite(log_accept_ratio) ? log_accept_ratio : -INFINITY;
     lap = fmin(lap, 0.0);
     const double accept = (lap > -INFINITY) ? exp(lap) : 0.0;
@@ -112,30 +126,33 @@ __device__ inline void dual_averaging(const SamplerCfgDev& cfg, ChainCtl& c, dou
     else if (prev > cfg.n_adapt) new_ss = c.da_step_size;
     else new_ss = exp(new_log_avg);
     if (prev > cfg.n_adapt) { new_err = c.da_error_sum; new_log_avg = c.da_log_avg; }
-    c.da_step_size = new_ss;
-    c.da_error_sum = new_err;
-    c.da_log_avg = new_log_avg;
-    c.da_step = prev + 1;
+    out[0] = log_accept_ratio;
+    out[1] = new_ss;
+    out[2] = new_err;
+    out[3] = new_log_avg;
 }
 
 __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevChains ch, SamplerCfgDev cfg) {
-    __shared__ double sh[(2 + MAGI_MAX_D + MAGI_MAX_P) * 16];
+    __shared__ double sh[(3 + MAGI_MAX_D + MAGI_MAX_P) * 16];
+    __shared__ double shs[16];
     if (ch.gctl->all_done) return;
     const int chain = blockIdx.x;
+    const int tid = threadIdx.x;
     ChainCtl c = ch.ctl[chain];
     const int dim = pb.dim;
     const int stop_k = min(ch.gctl->stop_k, cfg.total);
     const int epoch = ch.gctl->epoch;
     double* vb = ch.vec + vec_off(pb, chain, 0);
+    double* par = ch.par + (size_t)chain * PAR_COUNT;
     const TailVecs v = tail_vecs(pb, vb);
 
     if (c.phase == PH_IDLE) {
         if (c.k < stop_k) {            // resumed by a later magi_sampler_run
-            begin_sample(pb, cfg, c, v, sh);
-            if (threadIdx.x == 0) ch.ctl[chain] = c;
+            begin_sample(pb, cfg, c, v, par, sh, shs);
+            if (tid == 0) ch.ctl[chain] = c;
         } else if (c.done_epoch != epoch) {
             c.done_epoch = epoch;
-            if (threadIdx.x == 0) {
+            if (tid == 0) {
                 ch.ctl[chain] = c;
                 const int done = atomicAdd(&ch.gctl->done_chains, 1) + 1;
                 if (done >= ch.gctl->n_chains) ch.gctl->all_done = 1;
@@ -144,19 +161,26 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
         return;
     }
 
+    // data-independent uniforms of this leaf / a possible merge: drawn early by two idle waves
+    if (c.phase == PH_LEAF) {
+        if (tid == 64) shs[8] = log1p(-rng_uniform((unsigned)c.leaf_ctr, (unsigned)c.k, (unsigned)c.chain_id, STREAM_LEAF, cfg.seed));
+        if (tid == 128) shs[9] = log1p(-rng_uniform((unsigned)c.depth, (unsigned)c.k, (unsigned)c.chain_id, STREAM_MERGE, cfg.seed));
+    }
+
     // ---- 1. finish the gradient at V_Q ---------------------------------------------------------
-    const FinalizeOut fo = finalize_gradient(pb, vb, sh);
+    const FinalizeOut fo = finalize_gradient(pb, vb, par, sh, shs);
     const double L = fo.L;
 
     if (c.phase == PH_INIT) {
         // bootstrap_results: target / gradient at the initial state, cached at beta_temp(0)
-        for (int e = threadIdx.x; e < dim; e += blockDim.x) { v.candq[e] = v.q[e]; v.candg[e] = v.g[e]; }
-        c.cand_L = L;
-        c.beta_cache = cfg.anneal ? temperature(0, cfg.min_temp) : 1.0;
+        for (int e = tid; e < dim; e += blockDim.x) { v.candq[e] = v.q[e]; v.candg[e] = v.g[e]; }
+        if (tid == 0) shs[5] = cfg.anneal ? temperature(0, cfg.min_temp) : 1.0;
         __syncthreads();
-        if (c.k < stop_k) begin_sample(pb, cfg, c, v, sh);
+        c.cand_L = L;
+        c.beta_cache = shs[5];
+        if (c.k < stop_k) begin_sample(pb, cfg, c, v, par, sh, shs);
         else c.phase = PH_IDLE;
-        if (threadIdx.x == 0) ch.ctl[chain] = c;
+        if (tid == 0) ch.ctl[chain] = c;
         return;
     }
 
@@ -170,7 +194,7 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
     double* ckp_w = v.ckp + (size_t)__popc((unsigned)it) * pb.dimp;
     double* ckr_w = v.ckrho + (size_t)__popc((unsigned)it) * pb.dimp;
     double pp[1] = {0.0};
-    for (int e = threadIdx.x; e < dim; e += blockDim.x) {
+    for (int e = tid; e < dim; e += blockDim.x) {
         const double pn = v.p[e] + hs * v.g[e];
         v.p[e] = pn;
         const double rs = v.rhosub[e] + pn;
@@ -187,7 +211,7 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
             const double* cp = v.ckp + (size_t)__popc((unsigned)left) * pb.dimp;
             const double* cr = v.ckrho + (size_t)__popc((unsigned)left) * pb.dimp;
             double dots[2] = {0.0, 0.0};
-            for (int e = threadIdx.x; e < dim; e += blockDim.x) {
+            for (int e = tid; e < dim; e += blockDim.x) {
                 const double df = v.rhosub[e] - cr[e];
                 dots[0] = fma(df, cp[e], dots[0]);
                 dots[1] = fma(df, v.p[e], dots[1]);
@@ -202,13 +226,16 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
     if (isnan(energy)) energy = -INFINITY;
     const double ediff = energy - c.init_energy;
     const bool not_divergent = (-ediff < cfg.max_energy_diff);
+    if (tid == 0) shs[10] = logaddexp(c.sub_weight, ediff);
+    if (tid == 192) shs[11] = exp(fmin(ediff, 0.0));
+    __syncthreads();
     {
-        const double wsum = logaddexp(c.sub_weight, ediff);
+        const double wsum = shs[10];
         const double thresh = ediff - wsum;
-        const double u = log1p(-rng_uniform((unsigned)c.leaf_ctr, (unsigned)c.k, (unsigned)c.chain_id, STREAM_LEAF, cfg.seed));
+        const double u = shs[8];
         c.leaf_ctr += 1;
         if (u <= thresh) {
-            for (int e = threadIdx.x; e < dim; e += blockDim.x) { v.subq[e] = v.q[e]; v.subg[e] = v.g[e]; }
+            for (int e = tid; e < dim; e += blockDim.x) { v.subq[e] = v.q[e]; v.subg[e] = v.g[e]; }
             c.sub_L = L;
             c.sub_energy = energy;
         }
@@ -217,35 +244,37 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
     const bool cont_tree = not_divergent && (c.cont != 0);
     c.cont = (no_u && cont_tree) ? 1 : 0;
     c.nd = (c.nd && not_divergent) ? 1 : 0;
-    if (cont_tree) c.e_sum_sub += exp(fmin(ediff, 0.0));
+    if (cont_tree) c.e_sum_sub += shs[11];
     c.sub_lf += 1;
     c.it = it + 1;
 
     if (c.it < c.nsteps && c.cont) {
         // ---- 4a. next leaf of the same subtree: half step + position update -----------------------
-        for (int e = threadIdx.x; e < dim; e += blockDim.x) {
+        for (int e = tid; e < dim; e += blockDim.x) {
             const double ph = v.p[e] + hs * v.g[e];
             v.p[e] = ph;
-            v.q[e] = v.q[e] + eps * ph;
+            const double qn = v.q[e] + eps * ph;
+            v.q[e] = qn;
+            if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par);
         }
-        if (threadIdx.x == 0) ch.ctl[chain] = c;
+        if (tid == 0) ch.ctl[chain] = c;
         return;
     }
 
     // ---- 4b. subtree finished: merge into the trajectory (biased progressive sampling) --------------
+    const double tree_weight = c.cont ? c.sub_weight : -INFINITY;
     __syncthreads();
+    if (tid == 0) shs[12] = logaddexp(tree_weight, c.cand_weight);
     {
-        const double tree_weight = c.cont ? c.sub_weight : -INFINITY;
-        const double wsum = logaddexp(tree_weight, c.cand_weight);
         const double thresh = tree_weight - c.cand_weight;
-        const double u = log1p(-rng_uniform((unsigned)c.depth, (unsigned)c.k, (unsigned)c.chain_id, STREAM_MERGE, cfg.seed));
+        const double u = shs[9];
         const bool choose = (u <= thresh) && (c.cont != 0);
         double* pe = (c.dir > 0) ? v.pR : v.pL;
         double* qe = (c.dir > 0) ? v.qR : v.qL;
         double* ge = (c.dir > 0) ? v.gR : v.gL;
         const double* po = (c.dir > 0) ? v.pL : v.pR;    // the other end
         double dots[2] = {0.0, 0.0};
-        for (int e = threadIdx.x; e < dim; e += blockDim.x) {
+        for (int e = tid; e < dim; e += blockDim.x) {
             if (choose) { v.candq[e] = v.subq[e]; v.candg[e] = v.subg[e]; }
             const double pn = v.p[e];
             pe[e] = pn; qe[e] = v.q[e]; ge[e] = v.g[e];
@@ -254,9 +283,9 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
             dots[0] = fma(rr, po[e], dots[0]);
             dots[1] = fma(rr, pn, dots[1]);
         }
-        block_sum<2>(dots, sh);
+        block_sum<2>(dots, sh);        // (barriers publish shs[12])
         if (choose) { c.cand_L = c.sub_L; c.cand_energy = c.sub_energy; c.cand_bfac = c.beta_k; c.is_accepted = 1; }
-        c.cand_weight = wsum;
+        c.cand_weight = shs[12];
         if (c.dir > 0) { c.LR = c.L_cur; c.bfacR = c.beta_k; } else { c.LL = c.L_cur; c.bfacL = c.beta_k; }
         const bool no_u_traj = (dots[0] > 0.0) && (dots[1] > 0.0);
         c.e_sum += c.e_sum_sub;
@@ -265,15 +294,17 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
         c.depth += 1;
         const bool continue_tree = (c.cont != 0) && no_u_traj;
         if (c.depth < cfg.max_depth && continue_tree) {
-            begin_doubling(pb, cfg, c, v);
-            if (threadIdx.x == 0) ch.ctl[chain] = c;
+            begin_doubling(pb, cfg, c, v, par);
+            if (tid == 0) ch.ctl[chain] = c;
             return;
         }
 
         // ---- 5. transition finished -----------------------------------------------------------------
-        const double lar = log(c.e_sum / (double)c.lf_count);
+        if (tid == 0) dual_averaging_eval(cfg, c, c.e_sum, c.lf_count, &shs[0]);
+        __syncthreads();
+        const double lar = shs[0];
         const int k = c.k;
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             const size_t o = (size_t)chain * cfg.total + k;
             ch.d_step_size[o] = c.eps;
             ch.d_lar[o] = lar;
@@ -286,25 +317,27 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
         }
         if (k >= cfg.burnin) {
             double* out = ch.samples + ((size_t)chain * (cfg.total - cfg.burnin) + (k - cfg.burnin)) * pb.dimp;
-            for (int e = threadIdx.x; e < dim; e += blockDim.x) out[e] = v.candq[e];
+            for (int e = tid; e < dim; e += blockDim.x) out[e] = v.candq[e];
         }
         if (c.is_accepted) c.beta_cache = c.beta_k;
-        dual_averaging(cfg, c, lar);
+        c.da_step_size = shs[1];
+        c.da_error_sum = shs[2];
+        c.da_log_avg = shs[3];
+        c.da_step += 1;
         c.k = k + 1;
     }
-    __syncthreads();
     if (c.k >= stop_k) {
         c.phase = PH_IDLE;
         c.done_epoch = epoch;
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             ch.ctl[chain] = c;
             const int done = atomicAdd(&ch.gctl->done_chains, 1) + 1;
             if (done >= ch.gctl->n_chains) ch.gctl->all_done = 1;
         }
         return;
     }
-    begin_sample(pb, cfg, c, v, sh);
-    if (threadIdx.x == 0) ch.ctl[chain] = c;
+    begin_sample(pb, cfg, c, v, par, sh, shs);
+    if (tid == 0) ch.ctl[chain] = c;
 }
 
 __global__ void k_init_chains(DevChains ch, SamplerCfgDev cfg, const long long* chain_ids) {
