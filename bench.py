@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: HMC (NUTS) samples/sec on synthetic SEIR, N grid points x 4 components.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): SEIR-4 (S, E, I, R explicit), N = 1024
+grid points (dt = 0.025, observations at even indices, noise 0.05 * range, PCG64(0)), dense
+matrices, hyper-parameters at the reference's starting values, theta_init = (1, 1, 1), NUTS (max
+tree depth 10) with dual averaging and the logarithmic annealing schedule -- i.e. the reference's
+predict() sampler (magi_v2.py:357-396) -- one chain per GPU.  A "step" is one NUTS transition of
+every chain on the rank.  Setup (data, GPU matrix build, burn-in/adaptation) is untimed; the timed
+region is exactly K transitions with all inputs resident in HBM.
+
+One rank per GPU (torchrun); chains are independent (no data-path collective); the post-burn-in
+samples of all ranks are gathered once to rank 0 over RCCL after the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch            # first: owns the HIP runtime the extension then shares
+import torch.distributed as dist
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=1024, help="N grid points")
+    ap.add_argument("--chains-per-gpu", type=int, default=1)
+    ap.add_argument("--burnin", type=int, default=40, help="untimed adaptation steps before warmup")
+    ap.add_argument("--band", type=int, default=-1, help="bandsize (-1 = dense)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2, help="oracle NUTS transitions for the CPU baseline")
+    ap.add_argument("--seed", type=int, default=20250103)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from magi_v2_amd import host
+    from magi_v2_amd.engine import MagiEngine
+
+    N, D, P = a.grid, 4, 3
+    cpg = a.chains_per_gpu
+    band = None if a.band < 0 else a.band
+
+    # ---- setup (untimed) -----------------------------------------------------------------------
+    I, X_obs, truth, theta_true = host.synthetic_seir(N, seed=0)
+    Xi = host.linear_interpolate(X_obs)
+    hp = host.hparams_initial(Xi)
+    N_ds, beta, idx, y = host.observation_bookkeeping(X_obs, X_obs)
+    Xhat = host.cubic_smoother(I, Xi)
+    LB = host.sigma_sqs_lower_bound(Xhat)
+    sig_pre0, th_pre0 = host.softplus_inverse_inits(hp["sigma_sqs"], np.ones(P), LB)
+
+    eng = MagiEngine(local_rank)
+    t0 = time.perf_counter()
+    want_host = (rank == 0 and world == 1 and not a.no_cpu_baseline)
+    mats = eng.build_matrices(I, hp["phi1s"], hp["phi2s"], 2.01, bandsize=band, want_host=want_host)
+    build_ms = (time.perf_counter() - t0) * 1e3
+    eng.set_problem(Xi.mean(axis=0), N_ds.astype(np.float64), idx, y, beta, LB, "seir4")
+
+    total = a.burnin + a.warmup + a.steps
+    # stale_cache=0: the reference's annealed kernel reuses the previous step's cached target, which
+    # was computed at the previous temperature (SURVEY section 7 quirk ii); on this synthetic grid the
+    # log posterior is positive, which makes that offset reject every proposal, so the bench runs
+    # the recomputing variant (same arithmetic per leapfrog, see DESIGN.md "stale cache").
+    cfg = eng.default_cfg(num_results=a.warmup + a.steps, num_burnin_steps=a.burnin, stale_cache=0)
+    rep = lambda v: np.repeat(np.asarray(v)[None], cpg, axis=0)
+    chain_ids = [rank * cpg + i for i in range(cpg)]
+    eng.sampler_init(cfg, rep(Xhat), rep(sig_pre0), rep(th_pre0), seed=a.seed, chain_ids=chain_ids)
+    eng.sampler_run(a.burnin)
+    if a.warmup > 0:
+        eng.sampler_run(a.warmup)
+
+    # ---- timed region: exactly K transitions -------------------------------------------------------
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lf, dev_ms = eng.sampler_run(a.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    lfs = torch.tensor([float(lf)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lfs, op=dist.ReduceOp.SUM)
+    elapsed = float(tmax.item())
+    lf_total = float(lfs.item())
+
+    # ---- final sample gather over RCCL (the only collective of the job) -------------------------------
+    Xs, sp, tp = eng.sampler_samples()
+    gather_ms = 0.0
+    th_all = tp
+    if world > 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        flat = np.concatenate([Xs.reshape(cpg, Xs.shape[1], -1), sp, tp], axis=2)
+        mine = torch.from_numpy(flat).cuda()
+        bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, bufs, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - t1) * 1e3
+        if rank == 0:
+            th_all = torch.cat(bufs, dim=0).cpu().numpy()[:, :, -P:]
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    n_chains = cpg * world
+    value = n_chains * a.steps / elapsed
+    diag = eng.sampler_diag()
+    post = diag.tree_depth[:, a.burnin + a.warmup:]
+
+    # ---- roofline of the dominant kernel (phase-1 mat-vec), HIP events on the engine's stream -----------
+    grad_ms, phase_ms = eng.time_gradient(cpg, 300)
+    phase_bytes = eng.gradient_bytes(cpg)
+    achieved = phase_bytes[0] / (phase_ms[0] * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_matvec_dense<1> (phase 1: Csym x, M x)" if band is None or 2 * band + 1 >= N else "k_matvec_band<1>",
+                "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+                "traffic": None, "bytes_per_launch": phase_bytes[0], "us_per_launch": round(phase_ms[0] * 1e3, 3),
+                "all_phases_us": [round(x * 1e3, 3) for x in phase_ms], "all_phases_GBps": [round(b / (t * 1e-3) / 1e9, 1) for b, t in zip(phase_bytes, phase_ms)],
+                "gradient_eval_us": round(grad_ms * 1e3, 3)}
+
+    # ---- CPU baseline: the numpy oracle continues the SAME chain from the GPU's current state -----------
+    cpu = None
+    if world == 1 and not a.no_cpu_baseline:
+        from oracle import magi_oracle as orc
+        import threadpoolctl
+        C_inv, m, K_inv = mats
+        pr = orc.Problem(I=I, mu=Xi.mean(axis=0), C_inv=orc.band_part(C_inv, band), m=orc.band_part(m, band),
+                         K_inv=orc.band_part(K_inv, band), N_ds=N_ds.astype(np.float64), obs_idx=idx, y=y, beta=float(beta),
+                         LB=LB, drift="seir4", P=P)
+        Xc, spc, tpc, ss, bc = eng.sampler_state()
+        q = orc.pack(Xc[0], spc[0], tpc[0])
+        fn_L = orc.make_fn_L(pr)
+        L, gL = fn_L(q)
+        k = total
+        tc0 = time.perf_counter()
+        n_lf = 0
+        for s in range(a.cpu_steps):
+            temp = orc.temperature(k + s)
+            res = orc.nuts_one_step(q, temp * L, temp * gL, float(ss[0]), temp, fn_L, k + s, chain_ids[0], a.seed)
+            n_lf += res.leapfrogs
+            if res.is_accepted:
+                q, L, gL = res.q, res.L, res.gL
+        cpu_s = time.perf_counter() - tc0
+        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] + [1])
+        cpu = {"value": round(a.cpu_steps / cpu_s, 5), "unit": "samples/s", "cores": threads, "kind": "port",
+               "sample": f"{a.cpu_steps} NUTS transitions ({n_lf} leapfrogs) of the same chain continued from the GPU state by "
+                         "oracle/magi_oracle.py (numpy + OpenBLAS restatement of magi_v2.py:308-348 and TFP NUTS)",
+               "leapfrogs_per_s": round(n_lf / cpu_s, 2), "host_cpus": os.cpu_count()}
+
+    out = {
+        "metric": "HMC samples/sec (whole node) on SEIR, N grid pts x D comps",
+        "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"SEIR N={N} x 4 components, {'dense' if band is None else 'band ' + str(band)}, "
+                               f"NUTS(max depth 10)+dual averaging+log annealing, {cpg} chain(s)/GPU",
+                   "grid": N, "components": D, "thetas": P, "chains_total": n_chains, "bandsize": band,
+                   "burnin_untimed": a.burnin, "parallelism": f"chains x{world}"},
+        "roofline": roofline, "cpu_baseline": cpu,
+        "leapfrogs_per_s": round(lf_total / elapsed, 1), "us_per_leapfrog_slot": round(elapsed / (lf_total / n_chains) * 1e6, 2),
+        "mean_tree_depth": round(float(post.mean()), 2), "device_ms": round(dev_ms, 2), "build_ms": round(build_ms, 1),
+        "gather_ms": round(gather_ms, 3), "theta_mean": [round(float(x), 4) for x in np.log1p(np.exp(th_all)).reshape(-1, P).mean(axis=0)],
+    }
+    if cpu:
+        out["speedup_vs_cpu_port"] = round(value / cpu["value"], 1)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

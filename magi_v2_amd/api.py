@@ -1,0 +1,260 @@
+"""Drop-in for the Python surface of the reference's ``magi_v2.MAGI_v2`` (magi_v2.py:20-462).
+
+Same constructor, methods, public attributes and results dictionary; the hot path -- kernel
+matrices, log posterior + gradient, NUTS -- runs in libmagi_hip.so on an MI355X.  There is no
+CPU implementation of that path in this package: without the library or a GPU the methods raise.
+
+What differs from the reference, deliberately:
+  * ``f_vec`` is a built-in drift name or a numpy-compatible callable that matches one
+    (host.resolve_drift); TensorFlow is not a dependency.
+  * hyper-parameters: ``initial_fit`` uses the reference's *starting* values (var, Fourier prior
+    mean, (0.1 std)^2 -- magi_v2.py:631-639) unless ``hparams=`` is given; the TFP marginal
+    likelihood fit (magi_v2.py:538-691) is SURVEY.md section 8 row f1 (next).
+  * ``predict`` takes keyword-only extras (n_chains, seed, ...); defaults reproduce the reference.
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Optional, Sequence, Union
+
+import numpy as np
+
+from . import host
+from .engine import DRIFT_SHAPES, MagiEngine
+
+
+def logarithmic_temperature_schedule(step, min_temp: float = 0.1):
+    """magi_v2.py:833-835."""
+    return np.maximum(1.0 / np.log(np.asarray(step, dtype=np.float64) + 2.0), min_temp)
+
+
+def _band(A: np.ndarray, b: Optional[int]) -> np.ndarray:
+    if b is None:
+        return A
+    n = A.shape[-1]
+    i = np.arange(n)
+    return A * (np.abs(i[:, None] - i[None, :]) <= b)
+
+
+def _fingerprint(*arrays) -> tuple:
+    out = []
+    for a in arrays:
+        a = np.asarray(a)
+        flat = a.reshape(-1)
+        step = max(1, flat.shape[0] // 4096)
+        out.append((a.shape, float(flat[::step].sum()), float(flat[-1]), float(flat[0])))
+    return tuple(out)
+
+
+class MAGI_v2:
+    """MAnifold-constrained Gaussian-process Inference on an MI355X (interface of magi_v2.py:20-73)."""
+
+    def __init__(self, D_thetas: int, ts_obs: np.ndarray, X_obs: np.ndarray, bandsize: Union[int, None],
+                 f_vec: Union[str, Callable], device: int = 0):
+        self.D_thetas = D_thetas
+        self.BANDSIZE = bandsize
+        self.ts_obs = ts_obs
+        self.X_obs = X_obs
+        self.N, self.D = self.X_obs.shape
+
+        # observed vs completely unobserved components (magi_v2.py:45-50)
+        self.observed_indicators = (~np.isnan(X_obs)).mean(axis=0) > 0
+        self.observed_components = np.arange(self.D)[self.observed_indicators]
+        self.D_observed = len(self.observed_components)
+        self.unobserved_components = np.setdiff1d(np.arange(self.D), self.observed_components)
+        self.D_unobserved = len(self.unobserved_components)
+        self.proper_order = np.argsort(np.concatenate([self.observed_components, self.unobserved_components]))
+        self.N_ds = (~np.isnan(self.X_obs)).sum(axis=0)                       # magi_v2.py:53
+
+        self.I, self.X_obs_discret = None, None
+        self.beta, self.mag_I = None, None
+        self.not_nan_idxs, self.not_nan_cols = None, None
+        self.y_tau_ds_observed = None
+        self.X_interp_obs, self.X_interp_unobs = None, None
+
+        self.phi1s = np.full((self.D,), np.nan)
+        self.phi2s = np.full((self.D,), np.nan)
+        self.sigma_sqs_init = np.full((self.D,), np.nan)
+        self.Xhat_init, self.thetas_init = None, None
+        self.mu_ds = np.full((self.D,), np.nan)
+        self.C_d_invs, self.m_ds, self.K_d_invs = None, None, None
+
+        self.f_vec = f_vec
+        self.drift = host.resolve_drift(f_vec, self.D, D_thetas)
+        self._device = device
+        self._engine: Optional[MagiEngine] = None
+        self._resident = None       # fingerprint of the matrices currently on the device
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def engine(self) -> MagiEngine:
+        if self._engine is None:
+            self._engine = MagiEngine(self._device)      # raises without libmagi_hip.so / GPU
+        return self._engine
+
+    def _build(self, comps: Sequence[int], phi1s, phi2s):
+        """Eqn. 6 matrices for the listed components on the GPU (magi_v2.py:122-128, 262-268, 447-451)."""
+        C_inv, m, K_inv = self.engine.build_matrices(self.I, phi1s, phi2s, 2.01, bandsize=None)
+        for k, d in enumerate(comps):
+            self.C_d_invs[d], self.m_ds[d], self.K_d_invs[d] = C_inv[k], m[k], K_inv[k]
+
+    def _apply_band(self):
+        """magi_v2.py:271-274 / 459-462 (host copies; the device applies the same mask when loading)."""
+        if self.BANDSIZE is not None:
+            self.C_d_invs = _band(self.C_d_invs, self.BANDSIZE)
+            self.K_d_invs = _band(self.K_d_invs, self.BANDSIZE)
+            self.m_ds = _band(self.m_ds, self.BANDSIZE)
+
+    def _sync_matrices(self):
+        fp = _fingerprint(self.C_d_invs, self.m_ds, self.K_d_invs) + (self.BANDSIZE,)
+        if fp != self._resident:
+            self.engine.set_matrices(np.asarray(self.C_d_invs), np.asarray(self.m_ds), np.asarray(self.K_d_invs),
+                                     bandsize=self.BANDSIZE)
+            self._resident = fp
+
+    # ------------------------------------------------------------------------------------------
+    def initial_fit(self, discretization: int, verbose=False, hparams: Optional[dict] = None,
+                    theta_init_iters: int = 10000):
+        """magi_v2.py:82-277.  ``hparams`` may carry phi1s / phi2s / sigma_sqs (observed components)."""
+        self.I, self.X_obs_discret = host.discretize(self.ts_obs, self.X_obs, discretization)
+        self.mag_I = self.I.shape[0]
+        N_ds, self.beta, idx, y = host.observation_bookkeeping(self.X_obs, self.X_obs_discret)
+        self.not_nan_idxs = idx
+        self.not_nan_cols = idx % self.D
+        self.y_tau_ds_observed = y
+
+        self.X_interp_obs = host.linear_interpolate(self.X_obs_discret[:, self.observed_indicators])
+        hp = dict(host.hparams_initial(self.X_interp_obs))
+        if hparams is not None:
+            hp.update({k: np.asarray(v, dtype=np.float64) for k, v in hparams.items()})
+        self.phi1s[self.observed_indicators] = hp["phi1s"]
+        self.phi2s[self.observed_indicators] = hp["phi2s"]
+        self.sigma_sqs_init[self.observed_indicators] = hp["sigma_sqs"]
+        self.Xhat_init = self.X_obs_discret.copy()
+        self.Xhat_init[:, self.observed_indicators] = self.X_interp_obs
+        self.mu_ds[self.observed_indicators] = self.X_interp_obs.mean(axis=0)
+
+        self.C_d_invs = np.zeros((self.D, self.mag_I, self.mag_I))
+        self.m_ds = np.zeros((self.D, self.mag_I, self.mag_I))
+        self.K_d_invs = np.zeros((self.D, self.mag_I, self.mag_I))
+        self._build(self.observed_components, hp["phi1s"], hp["phi2s"])
+
+        if np.all(self.observed_indicators):
+            self.thetas_init = self._fit_thetas_init(theta_init_iters)
+        else:
+            raise NotImplementedError(
+                "completely unobserved components (magi_v2.py:182-268) are not supported yet "
+                "(SURVEY.md section 8, rows f2/f3); set X_obs columns or fill Xhat_init/thetas_init by hand")
+
+        self._apply_band()
+        self.Xhat_init = host.cubic_smoother(self.I, self.Xhat_init)
+        self._resident = None
+
+    def _fit_thetas_init(self, iters: int) -> np.ndarray:
+        """magi_v2.py:133-179: Adam(lr=.01) from theta = 1 on the t2 term, *including* the
+        reference's reshape (magi_v2.py:155-156 reinterprets the [N, D] drift as [D, N] instead of
+        transposing it).  The built-in drifts are linear in theta, so the objective is the
+        quadratic theta^T A theta - 2 b^T theta + c and Adam iterates on (A, b) exactly."""
+        P, D, n = self.D_thetas, self.D, self.mag_I
+        f_np = host.NUMPY_DRIFTS[self.drift]
+        cols = []
+        for p in range(P):
+            e = np.zeros(P); e[p] = 1.0
+            cols.append(f_np(self.I, self.Xhat_init, e).reshape(D, n))          # the reshape quirk
+        zero = f_np(self.I, self.Xhat_init, np.zeros(P))
+        assert np.abs(zero).max() == 0.0, "built-in drifts are homogeneous in theta"
+        F = np.stack(cols, axis=-1)                                              # [D, n, P]
+        Xc = (self.Xhat_init - self.mu_ds).T                                     # [D, n]
+        bvec = np.einsum("dij,dj->di", self.m_ds, Xc)                            # m_d x_c
+        KF = np.einsum("dij,djp->dip", self.K_d_invs, F)
+        KTF = np.einsum("dji,djp->dip", self.K_d_invs, F)
+        A = np.einsum("dip,diq->pq", F, KF)
+        g0 = np.einsum("dip,di->p", KF + KTF, bvec)                              # gradient offset
+        theta = np.ones(P)
+        m = np.zeros(P); v = np.zeros(P)
+        b1, b2, lr, eps = 0.9, 0.999, 0.01, 1e-7
+        for t in range(1, iters + 1):
+            grad = (A + A.T) @ theta - g0
+            m = b1 * m + (1 - b1) * grad
+            v = b2 * v + (1 - b2) * grad * grad
+            alpha = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+            theta = theta - alpha * m / (np.sqrt(v) + eps)
+        return theta
+
+    # ------------------------------------------------------------------------------------------
+    def predict(self, num_results: int = 1000, num_burnin_steps: int = 1000, sigma_sqs_LB=None, verbose=False, *,
+                n_chains: int = 1, seed: Optional[int] = None, chain_ids: Optional[Sequence[int]] = None,
+                stale_cache: bool = True, anneal: bool = True, max_tree_depth: int = 10, step_size: float = 0.1):
+        """magi_v2.py:286-425.  Returns the reference's results dictionary; with n_chains > 1 every
+        sample array gains a leading chain axis."""
+        assert ~np.any(np.isnan(self.Xhat_init)), "Please make sure Xhat_init does not have NaNs."
+        assert ~np.any(np.isnan(self.sigma_sqs_init)), "Please make sure sigma_sqs_init does not have NaNs."
+        assert ~np.any(np.isnan(self.thetas_init)), "Please make sure thetas_init does not have NaNs."
+
+        if sigma_sqs_LB is None:
+            sigma_sqs_LB = host.sigma_sqs_lower_bound(self.Xhat_init)
+        sigma_sqs_LB = np.asarray(sigma_sqs_LB, dtype=np.float64)
+        eng = self.engine
+        self._sync_matrices()
+        eng.set_problem(self.mu_ds, self.N_ds.astype(np.float64), np.asarray(self.not_nan_idxs),
+                        np.asarray(self.y_tau_ds_observed), float(self.beta), sigma_sqs_LB, self.drift)
+        sig_pre0, th_pre0 = host.softplus_inverse_inits(np.asarray(self.sigma_sqs_init, dtype=np.float64),
+                                                        np.asarray(self.thetas_init, dtype=np.float64), sigma_sqs_LB)
+        if seed is None:                 # the reference calls sample_chain unseeded (magi_v2.py:389-395)
+            seed = int(np.random.SeedSequence().generate_state(2, dtype=np.uint32).astype(np.uint64) @ np.array([1, 1 << 32], dtype=np.uint64))
+        cfg = eng.default_cfg(num_results=num_results, num_burnin_steps=num_burnin_steps, stale_cache=int(stale_cache),
+                              anneal=int(anneal), max_tree_depth=max_tree_depth, step_size=step_size)
+        rep = lambda a: np.repeat(np.asarray(a, dtype=np.float64)[None], n_chains, axis=0)
+        if verbose:
+            print("Starting NUTS posterior sampling ...")
+        start = time.time()
+        eng.sampler_init(cfg, rep(self.Xhat_init), rep(sig_pre0), rep(th_pre0), seed=seed, chain_ids=chain_ids)
+        eng.sampler_run(num_results + num_burnin_steps)
+        X_samps, sig_pre, th_pre = eng.sampler_samples()
+        end = time.time()
+        minutes = np.round((end - start) / 60, 2)
+        if verbose:
+            print(f"Finished sampling in {minutes} minutes.")
+        diag = eng.sampler_diag()
+        sig_samps, th_samps = host.transform_samples(sig_pre, th_pre, sigma_sqs_LB)
+        sq = (lambda a: a[0]) if n_chains == 1 else (lambda a: a)
+        B = num_burnin_steps
+        kernel_results = {k: sq(getattr(diag, k)[:, B:]) for k in
+                          ("step_size", "log_accept_ratio", "leapfrogs_taken", "tree_depth", "has_divergence",
+                           "reach_max_depth", "is_accepted", "target_log_prob", "energy", "beta_temp")}
+        kernel_results["seed"] = seed
+        return {"phi1s": self.phi1s, "phi2s": self.phi2s,
+                "Xhat_init": self.Xhat_init,
+                "sigma_sqs_init": self.sigma_sqs_init,
+                "thetas_init": self.thetas_init,
+                "I": self.I,
+                "X_samps": sq(X_samps),
+                "sigma_sqs_samps": sq(sig_samps),
+                "thetas_samps": sq(th_samps),
+                "kernel_results": kernel_results,
+                "sample_results": [sq(X_samps), sq(sig_pre), sq(th_pre)],
+                "minutes_elapsed": minutes}
+
+    # ------------------------------------------------------------------------------------------
+    def update_kernel_matrices(self, I_new, phi1s_new, phi2s_new):
+        """magi_v2.py:433-462: new grid + hyper-parameters -> rebuild every component's matrices."""
+        self.I = np.asarray(I_new, dtype=np.float64).reshape(-1, 1)
+        self.phi1s, self.phi2s = np.array(phi1s_new, dtype=np.float64), np.array(phi2s_new, dtype=np.float64)
+        self.mag_I = self.I.shape[0]
+        self.beta = (self.D * self.mag_I) / self.N_ds.sum()
+        self.C_d_invs = np.zeros((self.D, self.mag_I, self.mag_I))
+        self.m_ds = np.zeros((self.D, self.mag_I, self.mag_I))
+        self.K_d_invs = np.zeros((self.D, self.mag_I, self.mag_I))
+        self._build(range(self.D), self.phi1s, self.phi2s)
+        self._apply_band()
+        self._resident = None
+
+    # reference helper names kept for callers that reach into them
+    def _discretize(self, ts_obs, X_obs, discretization):
+        return host.discretize(ts_obs, X_obs, discretization)
+
+    def _linear_interpolate(self, X_partial):
+        return host.linear_interpolate(X_partial)
+
+    def cv_cubic_smoother(self, I, X_filled):
+        return host.cubic_smoother(I, X_filled)
