@@ -85,7 +85,8 @@ def main():
     # the recomputing variant (same arithmetic per leapfrog, see DESIGN.md "stale cache").
     cfg = eng.default_cfg(num_results=a.warmup + a.steps, num_burnin_steps=a.burnin, stale_cache=0)
     rep = lambda v: np.repeat(np.asarray(v)[None], cpg, axis=0)
-    chain_ids = [rank * cpg + i for i in range(cpg)]
+    from magi_v2_amd.shard import chain_ids_for_rank
+    chain_ids = chain_ids_for_rank(rank, world, cpg * world)
     eng.sampler_init(cfg, rep(Xhat), rep(sig_pre0), rep(th_pre0), seed=a.seed, chain_ids=chain_ids)
     eng.sampler_run(a.burnin)
     if a.warmup > 0:
@@ -110,20 +111,15 @@ def main():
     lf_total = float(lfs.item())
 
     # ---- final sample gather over RCCL (the only collective of the job) -------------------------------
+    from magi_v2_amd.shard import gather_samples
     Xs, sp, tp = eng.sampler_samples()
-    gather_ms = 0.0
-    th_all = tp
-    if world > 1:
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        flat = np.concatenate([Xs.reshape(cpg, Xs.shape[1], -1), sp, tp], axis=2)
-        mine = torch.from_numpy(flat).cuda()
-        bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine, bufs, dst=0)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - t1) * 1e3
-        if rank == 0:
-            th_all = torch.cat(bufs, dim=0).cpu().numpy()[:, :, -P:]
+    flat = np.concatenate([Xs.reshape(cpg, Xs.shape[1], -1), sp, tp], axis=2)     # [chains, results, N*D + D + P]
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    allsamp, gids = gather_samples(flat, chain_ids, dst=0)
+    torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - t1) * 1e3 if world > 1 else 0.0
+    th_all = allsamp[:, :, -P:] if rank == 0 else None
 
     if rank != 0:
         if world > 1:

@@ -131,3 +131,33 @@ def test_state_init_and_transforms():
     assert orc.temperature(0) == pytest.approx(1.0 / np.log(2.0))
     assert orc.temperature(1) == pytest.approx(1.0 / np.log(3.0))
     assert orc.temperature(10 ** 6) == 0.1
+
+
+def test_oracle_nuts_samples_a_correlated_gaussian():
+    """The NUTS restatement is unpinned against TFP (see the oracle's header); this at least pins
+    it as a correct sampler: moments of a correlated 3-d Gaussian within Monte-Carlo error."""
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((3, 3))
+    cov = A @ A.T + 0.5 * np.eye(3)
+    prec = np.linalg.inv(cov)
+    mean = np.array([1.0, -2.0, 0.5])
+
+    def fn_L(q):
+        d = q - mean
+        return -0.5 * d @ prec @ d, -prec @ d
+
+    q = np.zeros(3)
+    L, gL = fn_L(q)
+    da = orc.dual_averaging_init(0.5)
+    draws = []
+    for k in range(1400):
+        res = orc.nuts_one_step(q, L, gL, da.step_size, 1.0, fn_L, k, 0, 77)
+        if res.is_accepted:
+            q, L, gL = res.q, res.L, res.gL
+        da = orc.dual_averaging_update(da, res.log_accept_ratio, 400)
+        if k >= 400:
+            draws.append(q.copy())
+    draws = np.array(draws)
+    assert np.abs(draws.mean(axis=0) - mean).max() < 0.25
+    assert np.abs(np.cov(draws.T) - cov).max() < 0.35 * np.abs(cov).max()
+    assert 0.55 < da.step_size < 3.0
