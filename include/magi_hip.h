@@ -96,6 +96,14 @@ int magi_logpost_grad(magi_handle* h, int n_chains, const double* X, const doubl
                       const double* th_pre, double beta_temp,
                       double* logp, double* gX, double* gsig, double* gth, double* terms);
 
+/* Same quantity through the sampler's single-phase formulation: operators
+ * FH = Csym + m^T Ksym m, FE = Ksym m, FE^T, Ksym are applied to xc and f(X, theta) in ONE streaming
+ * kernel.  Exposed so the formulation the sampler runs can be validated against the reference
+ * op order above; terms = {t1 + t2, 0, t3, t4}. */
+int magi_logpost_grad_fused(magi_handle* h, int n_chains, const double* X, const double* sig_pre,
+                            const double* th_pre, double beta_temp,
+                            double* logp, double* gX, double* gsig, double* gth, double* terms);
+
 /* ---- sampler ------------------------------------------------------------------------------ */
 
 /* Replaces the TFP wiring of predict (magi_v2.py:357-396) and LogAnnealedNUTS
@@ -161,14 +169,19 @@ int magi_sample(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains,
 /* ---- instrumentation (bench.py roofline leg) ----------------------------------------------- */
 
 /* Launch one gradient evaluation (the 3 mat-vec phases + reduce) `reps` times on the handle's
- * stream, bracketed by HIP events on that stream; phase_ms[4] receives the average device
- * time per launch of phase 1, 2, 3 and the reduce kernel, measured in separate event-bracketed
- * loops.  Uses the states currently on the device (n_chains as last set). */
+ * stream, bracketed by HIP events on that stream; phase_ms[6] receives the average device
+ * time per launch of phase 1, 2, 3, the reduce kernel, the sampler's single-phase mat-vec kernel
+ * and its reduce, measured in separate event-bracketed loops.  Uses the states currently on the
+ * device (n_chains as last set). */
 int magi_time_gradient(magi_handle* h, int n_chains, int reps, double* total_ms_per_eval, double* phase_ms);
 
-/* Algorithmic HBM bytes of one gradient evaluation for the current matrices and n_chains,
- * per phase [4] (DESIGN.md section "bytes per unit"). */
+/* Bytes each of those six kernels must move per launch for the current matrices and n_chains
+ * (DESIGN.md section 4.1). */
 int magi_gradient_bytes(magi_handle* h, int n_chains, double* phase_bytes);
+
+/* Diagnostics: the 64-double transformed-parameter block of a chain (softplus / sigmoid / log
+ * terms of the state in flight; in a -DMAGI_TAIL_STAMPS build entries 40.. hold timing stamps). */
+int magi_debug_par(magi_handle* h, int chain, double* out64);
 
 #ifdef __cplusplus
 }

@@ -38,8 +38,8 @@ def build_lib(force=False, verbose=True):
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
                 and all(os.path.getmtime(obj) > os.path.getmtime(hh) for hh in hdrs)):
             continue
-        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function",
-               "-c", src, "-o", obj]
+        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function"] + \
+            os.environ.get("MAGI_EXTRA_CFLAGS", "").split() + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -358,9 +358,9 @@ struct Linalg {
     int* status = nullptr;
 };
 
-int launch_gemm(magi_handle* h, hipStream_t s, const GemmArgs& g) {
+int launch_gemm(magi_handle* h, hipStream_t s, const GemmArgs& g, int batch = 1) {
     if (g.M <= 0 || g.N <= 0) return MAGI_OK;
-    dim3 grid((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, 1);
+    dim3 grid((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, batch);
     hipLaunchKernelGGL(k_gemm_f64, grid, dim3(256), 0, s, g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("gemm launch: ") + hipGetErrorString(e));
@@ -519,6 +519,23 @@ struct DevBuf {
 };
 
 }  // namespace
+
+int magi_fused_operators(magi_handle* h, int N, int D, double* dCs_inout_H, const double* dM, const double* dKs, double* dE) {
+    const long nn = (long)N * N;
+    GemmArgs g{};     // E = Ks M
+    g.A = dKs; g.sAm = N; g.sAk = 1;
+    g.B = dM; g.sBn = 1; g.sBk = N;
+    g.C = dE; g.ldc = N; g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 0.0;
+    g.batchA = nn; g.batchB = nn; g.batchC = nn;
+    int rc = launch_gemm(h, h->stream, g, D);
+    if (rc) return rc;
+    GemmArgs t{};     // H = M^T E + Cs
+    t.A = dM; t.sAm = 1; t.sAk = N;
+    t.B = dE; t.sBn = 1; t.sBk = N;
+    t.C = dCs_inout_H; t.ldc = N; t.M = N; t.N = N; t.K = N; t.alpha = 1.0; t.beta = 1.0;
+    t.batchA = nn; t.batchB = nn; t.batchC = nn;
+    return launch_gemm(h, h->stream, t, D);
+}
 
 int magi_matern_blocks_device(magi_handle* h, const double* I, int N, double phi1, double phi2, double nu, double* Kappa,
                               double* p_Kappa, double* Kappa_pp) {

@@ -22,7 +22,10 @@ void free_dev(void* p) { if (p) (void)hipFree(p); }
 
 void free_matrices(magi_handle* h) {
     free_dev(h->dCsym); free_dev(h->dM); free_dev(h->dMt); free_dev(h->dKsym); free_dev(h->dYobs);
+    free_dev(h->dFH); free_dev(h->dFE); free_dev(h->dFEt); free_dev(h->dFK);
     h->dCsym = h->dM = h->dMt = h->dKsym = h->dYobs = nullptr;
+    h->dFH = h->dFE = h->dFEt = h->dFK = nullptr;
+    h->fused_elems = 0;
     h->have_matrices = h->have_problem = false;
 }
 
@@ -78,7 +81,7 @@ int build_graph(magi_handle* h) {
     MAGI_HIP_CHECK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     int rc = MAGI_OK;
     for (int s = 0; s < kGraphSlots && rc == MAGI_OK; ++s) {
-        rc = magi_launch_gradient(h, h->n_chains, h->stream);
+        rc = magi_launch_fused(h, h->n_chains, h->stream);
         if (rc == MAGI_OK) rc = magi_launch_tail(h, h->n_chains, h->stream);
     }
     hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
@@ -249,8 +252,8 @@ int magi_set_problem(magi_handle* h, const double* mu, const double* N_ds, const
     return MAGI_OK;
 }
 
-int magi_logpost_grad(magi_handle* h, int n_chains, const double* X, const double* sig_pre, const double* th_pre,
-                      double beta_temp, double* logp, double* gX, double* gsig, double* gth, double* terms) {
+static int logpost_grad_impl(magi_handle* h, bool fused, int n_chains, const double* X, const double* sig_pre, const double* th_pre,
+                             double beta_temp, double* logp, double* gX, double* gsig, double* gth, double* terms) {
     if (!h) return MAGI_E_BADARG;
     if (!X || !sig_pre || !th_pre) return magi_fail(h, MAGI_E_BADARG, "null state pointer");
     (void)hipSetDevice(h->device);
@@ -261,8 +264,13 @@ int magi_logpost_grad(magi_handle* h, int n_chains, const double* X, const doubl
     if ((rc = upload_states(h, n_chains, X, sig_pre, th_pre))) return rc;
     MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.gctl, 0, sizeof(GlobalCtl), h->stream));
     if ((rc = magi_launch_prepare(h, n_chains, h->stream))) return rc;
-    if ((rc = magi_launch_gradient(h, n_chains, h->stream))) return rc;
-    if ((rc = magi_launch_finalize(h, n_chains, h->d_fin, h->stream))) return rc;
+    if (fused) {
+        if ((rc = magi_launch_fused(h, n_chains, h->stream))) return rc;
+        if ((rc = magi_launch_finalize_fused(h, n_chains, h->d_fin, h->stream))) return rc;
+    } else {
+        if ((rc = magi_launch_gradient(h, n_chains, h->stream))) return rc;
+        if ((rc = magi_launch_finalize(h, n_chains, h->d_fin, h->stream))) return rc;
+    }
     MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     std::vector<double> fin((size_t)8 * n_chains), g((size_t)pb.dimp);
     MAGI_HIP_CHECK(h, hipMemcpy(fin.data(), h->d_fin, sizeof(double) * 8 * n_chains, hipMemcpyDeviceToHost));
@@ -276,6 +284,16 @@ int magi_logpost_grad(magi_handle* h, int n_chains, const double* X, const doubl
         }
     }
     return MAGI_OK;
+}
+
+int magi_logpost_grad(magi_handle* h, int n_chains, const double* X, const double* sig_pre, const double* th_pre,
+                      double beta_temp, double* logp, double* gX, double* gsig, double* gth, double* terms) {
+    return logpost_grad_impl(h, false, n_chains, X, sig_pre, th_pre, beta_temp, logp, gX, gsig, gth, terms);
+}
+
+int magi_logpost_grad_fused(magi_handle* h, int n_chains, const double* X, const double* sig_pre, const double* th_pre,
+                            double beta_temp, double* logp, double* gX, double* gsig, double* gth, double* terms) {
+    return logpost_grad_impl(h, true, n_chains, X, sig_pre, th_pre, beta_temp, logp, gX, gsig, gth, terms);
 }
 
 void magi_sampler_cfg_default(magi_sampler_cfg* cfg) {
@@ -356,7 +374,7 @@ int magi_sampler_init(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains,
     if ((rc = magi_launch_init_chains(h, h->d_chain_ids, h->stream))) return rc;
     // bootstrap_results: one gradient at the initial state (the tail stores it as the proposal)
     if ((rc = magi_launch_prepare(h, n_chains, h->stream))) return rc;
-    if ((rc = magi_launch_gradient(h, n_chains, h->stream))) return rc;
+    if ((rc = magi_launch_fused(h, n_chains, h->stream))) return rc;
     if ((rc = magi_launch_tail(h, n_chains, h->stream))) return rc;
     MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     h->epoch = 0;
@@ -413,7 +431,7 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
                 MAGI_HIP_CHECK(h, hipGraphLaunch(h->graph_exec, h->stream));
             } else {
                 for (int sl = 0; sl < kGraphSlots; ++sl) {
-                    if ((rc = magi_launch_gradient(h, h->n_chains, h->stream))) return rc;
+                    if ((rc = magi_launch_fused(h, h->n_chains, h->stream))) return rc;
                     if ((rc = magi_launch_tail(h, h->n_chains, h->stream))) return rc;
                 }
             }
@@ -515,6 +533,13 @@ int magi_sample(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains, const
     return magi_sampler_get_samples(h, X_samps, sig_pre_samps, th_pre_samps);
 }
 
+int magi_debug_par(magi_handle* h, int chain, double* out64) {
+    if (!h || !out64 || chain < 0 || chain >= h->n_chains) return MAGI_E_BADARG;
+    (void)hipSetDevice(h->device);
+    MAGI_HIP_CHECK(h, hipMemcpy(out64, h->ch.par + (size_t)chain * PAR_COUNT, sizeof(double) * PAR_COUNT, hipMemcpyDeviceToHost));
+    return MAGI_OK;
+}
+
 int magi_gradient_bytes(magi_handle* h, int n_chains, double* phase_bytes) {
     if (!h || !phase_bytes) return MAGI_E_BADARG;
     if (!h->have_matrices) return magi_fail(h, MAGI_E_STATE, "no matrices");
@@ -526,6 +551,9 @@ int magi_gradient_bytes(magi_handle* h, int n_chains, double* phase_bytes) {
     phase_bytes[1] = 1.0 * mat + 2.0 * vec;   // Ksym    ; read r, write Kr
     phase_bytes[2] = 1.0 * mat + 5.0 * vec;   // Mt      ; read Kr, X, Cx, yobs, write gX
     phase_bytes[3] = 5.0 * vec;               // reduce  ; read X, Cx, r, Kr, yobs
+    const double Wf = pb.bandf < 0 ? (double)pb.N : (double)(2 * pb.bandf + 1);
+    phase_bytes[4] = 4.0 * (double)pb.D * pb.N * Wf * 8.0 + 5.0 * vec;   // fused: FH, FE, FEt, FK ; read X, write 4 vectors
+    phase_bytes[5] = 9.0 * vec;               // fused reduce: X, 4 vectors, yobs, p, rho, write g
     return MAGI_OK;
 }
 
@@ -554,11 +582,13 @@ int magi_time_gradient(magi_handle* h, int n_chains, int reps, double* total_ms_
     MAGI_HIP_CHECK(h, hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
     if (total_ms_per_eval) *total_ms_per_eval = ms / reps;
     if (phase_ms) {
-        for (int ph = 1; ph <= 4; ++ph) {
+        for (int ph = 1; ph <= 6; ++ph) {
             MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t0, h->stream));
             for (int i = 0; i < reps; ++i) {
                 if (ph <= 3) rc = magi_launch_phase(h, ph, n_chains, h->stream);
-                else rc = magi_launch_finalize(h, n_chains, h->d_fin, h->stream);
+                else if (ph == 4) rc = magi_launch_finalize(h, n_chains, h->d_fin, h->stream);
+                else if (ph == 5) rc = magi_launch_fused(h, n_chains, h->stream);
+                else rc = magi_launch_finalize_fused(h, n_chains, h->d_fin, h->stream);
                 if (rc) return rc;
             }
             MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t1, h->stream));

@@ -14,7 +14,7 @@
 #define MAGI_MAX_D 4        // compiled-in drifts have D <= 4, P <= 5
 #define MAGI_MAX_P 6
 #define MAGI_MAX_DEPTH 12   // checkpoint slots for the iterative NUTS U-turn checks
-#define MAGI_TAIL_THREADS 1024
+#define MAGI_TAIL_THREADS 512
 #define MAGI_WAVE 64
 
 // ------------------------------------------------------------------------------------------
@@ -37,6 +37,11 @@ struct DevProblem {
     const double* Mt;     // [D][N][ld]  m^T
     const double* Ksym;   // [D][N][ld]  (K^-1 + K^-T)/2
     const double* yobs;   // [D][N], NaN = not observed        (magi_v2.py:96-100)
+    // single-phase ("fused") operators of the sampler, [D][N][ldf] each (see logpost.hip):
+    //   FH = Csym + m^T Ksym m,  FE = Ksym m,  FEt = FE^T,  FK = Ksym
+    const double *FH, *FE, *FEt, *FK;
+    int ldf;       // row pitch of the fused stacks; even
+    int bandf;     // -1 dense; else half-width 3b (products of band-b matrices)
 };
 
 // Per-chain vector slots (each dimp doubles) -------------------------------------------------
@@ -46,7 +51,8 @@ enum VecSlot {
     V_G,         // UNtempered gradient of L at V_Q
     V_CX,        // Csym * xc           [D][N]
     V_R,         // f - m xc            [D][N]
-    V_KR,        // Ksym * r            [D][N]
+    V_KR,        // Ksym * r            [D][N]   (fused path: Ksym * f)
+    V_ETF,       // fused path: FEt * f [D][N]   (V_CX holds FH * xc, V_R holds FE * xc)
     V_PL, V_QL, V_GL,       // left end of the trajectory
     V_PR, V_QR, V_GR,       // right end
     V_CANDQ, V_CANDG,       // trajectory-level proposal
@@ -163,31 +169,37 @@ __device__ inline double rng_uniform(unsigned int index, unsigned int step, unsi
     return u01_53(r.x, r.y);
 }
 
-__device__ inline double rng_normal_elem(unsigned int e, unsigned int step, unsigned int chain,
-                                         unsigned long long key) {
-    Philox4 r = philox4x32_10(e >> 1, step, chain, STREAM_MOMENTUM, key);
-    double u1 = u01_53(r.x, r.y), u2 = u01_53(r.z, r.w);
-    double rad = sqrt(-2.0 * log(u1));
-    double ang = 2.0 * 3.141592653589793 * u2;
-    return (e & 1) ? rad * sin(ang) : rad * cos(ang);
-}
+// ------------------------------------------------------------------------------------------
+// scalar helpers.  fp64 transcendentals are ~100-300-instruction sequences; the sampler's tail is
+// a run-once-per-launch kernel whose speed is set by instruction fetch, so each function exists
+// ONCE per translation unit (noinline) instead of once per call site.
+// ------------------------------------------------------------------------------------------
+static __device__ __noinline__ double m_log(double x) { return log(x); }
+static __device__ __noinline__ double m_exp(double x) { return exp(x); }
+static __device__ __noinline__ double m_log1p(double x) { return log1p(x); }
 
-// ------------------------------------------------------------------------------------------
-// scalar helpers
-// ------------------------------------------------------------------------------------------
-__device__ inline double softplus_ref(double x) { return log(1.0 + exp(x)); }   // magi_v2.py:318
-__device__ inline double sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }
+__device__ inline double softplus_ref(double x) { return m_log(1.0 + m_exp(x)); }   // magi_v2.py:318
+__device__ inline double sigmoid(double x) { return 1.0 / (1.0 + m_exp(-x)); }
 
 __device__ inline double logaddexp(double a, double b) {
     if (a == -INFINITY && b == -INFINITY) return -INFINITY;
     double t = a - b;
-    if (t > 0) return a + log1p(exp(-t));
-    if (t <= 0) return b + log1p(exp(t));
+    if (t > 0) return a + m_log1p(m_exp(-t));
+    if (t <= 0) return b + m_log1p(m_exp(t));
     return t;   // NaN
 }
 
 __device__ inline double temperature(int step, double min_temp) {   // magi_v2.py:833-835
-    return fmax(1.0 / log((double)step + 2.0), min_temp);
+    return fmax(1.0 / m_log((double)step + 2.0), min_temp);
+}
+
+__device__ inline double rng_normal_elem(unsigned int e, unsigned int step, unsigned int chain,
+                                         unsigned long long key) {
+    Philox4 r = philox4x32_10(e >> 1, step, chain, STREAM_MOMENTUM, key);
+    double u1 = u01_53(r.x, r.y), u2 = u01_53(r.z, r.w);
+    double rad = sqrt(-2.0 * m_log(u1));
+    double ang = 2.0 * 3.141592653589793 * u2;
+    return (e & 1) ? rad * sin(ang) : rad * cos(ang);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -207,7 +219,7 @@ __device__ inline void compute_par_entry(const DevProblem& pb, int j, double pre
         par[PAR_SIG2 + j] = s2;
         par[PAR_SGS + j] = sg;
         par[PAR_LJS + j] = pre - sp;
-        par[PAR_LOG2PIS + j] = log(2.0 * 3.141592653589793 * s2);
+        par[PAR_LOG2PIS + j] = m_log(2.0 * 3.141592653589793 * s2);
     } else {
         const int p = j - pb.D;
         par[PAR_TH + p] = sp;
@@ -305,6 +317,78 @@ __device__ __forceinline__ void drift_tt_g_acc(int drift, const double (&x)[MAGI
     }
     out[0] += o0; out[1] += o1; out[2] += o2; out[3] += o3; out[4] += o4;
 }
+
+// ------------------------------------------------------------------------------------------
+// Compile-time drifts for the sampler's kernels (D, P known -> no guards, no switch, small code)
+// ------------------------------------------------------------------------------------------
+template <int DRIFT> struct DriftT;
+
+template <> struct DriftT<MAGI_DRIFT_SEIR3> {
+    static constexpr int D = 3, P = 3;
+    static __device__ __forceinline__ void f(const double (&x)[3], const double (&th)[3], double (&o)[3]) {
+        const double E = x[0], I = x[1], R = x[2], S = 1.0 - ((E + I) + R);
+        o[0] = (th[0] * S * I) - (th[2] * E);
+        o[1] = (th[2] * E) - (th[1] * I);
+        o[2] = th[1] * I;
+    }
+    // c[d] = sum_d' g[d'] df_d'/dx_d ; t[p] += sum_d g[d] df_d/dtheta_p
+    static __device__ __forceinline__ void jt(const double (&x)[3], const double (&th)[3], const double (&g)[3], double (&c)[3], double (&t)[3]) {
+        const double E = x[0], I = x[1], R = x[2], S = 1.0 - ((E + I) + R);
+        const double b = th[0], gm = th[1], s = th[2];
+        c[0] = g[0] * (-b * I - s) + g[1] * s;
+        c[1] = g[0] * (b * S - b * I) - g[1] * gm + g[2] * gm;
+        c[2] = -g[0] * b * I;
+        t[0] += g[0] * S * I;
+        t[1] += (g[2] - g[1]) * I;
+        t[2] += (g[1] - g[0]) * E;
+    }
+};
+
+template <> struct DriftT<MAGI_DRIFT_SEIR4> {
+    static constexpr int D = 4, P = 3;
+    static __device__ __forceinline__ void f(const double (&x)[4], const double (&th)[3], double (&o)[4]) {
+        const double S = x[0], E = x[1], I = x[2];
+        o[0] = -th[0] * S * I;
+        o[1] = th[0] * S * I - th[2] * E;
+        o[2] = th[2] * E - th[1] * I;
+        o[3] = th[1] * I;
+    }
+    static __device__ __forceinline__ void jt(const double (&x)[4], const double (&th)[3], const double (&g)[4], double (&c)[4], double (&t)[3]) {
+        const double S = x[0], E = x[1], I = x[2];
+        const double b = th[0], gm = th[1], s = th[2];
+        c[0] = (g[1] - g[0]) * b * I;
+        c[1] = (g[2] - g[1]) * s;
+        c[2] = (g[1] - g[0]) * b * S + (g[3] - g[2]) * gm;
+        c[3] = 0.0;
+        t[0] += (g[1] - g[0]) * S * I;
+        t[1] += (g[3] - g[2]) * I;
+        t[2] += (g[2] - g[1]) * E;
+    }
+};
+
+template <> struct DriftT<MAGI_DRIFT_SIRW> {
+    static constexpr int D = 4, P = 5;
+    static __device__ __forceinline__ void f(const double (&x)[4], const double (&th)[5], double (&o)[4]) {
+        const double S = x[0], I = x[1], R = x[2], W = x[3];
+        o[0] = -th[0] * S * I + th[4] * W;
+        o[1] = th[0] * S * I - th[1] * I;
+        o[2] = th[1] * I - th[2] * R + th[3] * I * W;
+        o[3] = th[2] * R - th[3] * I * W - th[4] * W;
+    }
+    static __device__ __forceinline__ void jt(const double (&x)[4], const double (&th)[5], const double (&g)[4], double (&c)[4], double (&t)[5]) {
+        const double S = x[0], I = x[1], R = x[2], W = x[3];
+        const double be = th[0], ph = th[1], xi = th[2], ch = th[3], ka = th[4];
+        c[0] = (g[1] - g[0]) * be * I;
+        c[1] = -g[0] * be * S + g[1] * (be * S - ph) + g[2] * (ph + ch * W) - g[3] * ch * W;
+        c[2] = (g[3] - g[2]) * xi;
+        c[3] = g[0] * ka + g[2] * ch * I + g[3] * (-ch * I - ka);
+        t[0] += (g[1] - g[0]) * S * I;
+        t[1] += (g[2] - g[1]) * I;
+        t[2] += (g[3] - g[2]) * R;
+        t[3] += (g[2] - g[3]) * I * W;
+        t[4] += (g[0] - g[3]) * W;
+    }
+};
 
 // ------------------------------------------------------------------------------------------
 // reductions: 64-lane butterfly, then a fixed-order sum over the block's waves (deterministic)
@@ -488,6 +572,8 @@ struct magi_handle {
     DevProblem pb{};
     double *dCsym = nullptr, *dM = nullptr, *dMt = nullptr, *dKsym = nullptr, *dYobs = nullptr;
     size_t mat_elems = 0;
+    double *dFH = nullptr, *dFE = nullptr, *dFEt = nullptr, *dFK = nullptr;
+    size_t fused_elems = 0;
 
     // chains
     int n_chains = 0;
@@ -528,6 +614,10 @@ int magi_fail(magi_handle* h, int code, const std::string& msg);
 int magi_launch_gradient(magi_handle* h, int n_chains, hipStream_t s);        // phases 1-3
 int magi_launch_phase(magi_handle* h, int phase, int n_chains, hipStream_t s);
 int magi_launch_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s);
+int magi_launch_fused(magi_handle* h, int n_chains, hipStream_t s);            // single-phase mat-vecs
+int magi_launch_finalize_fused(magi_handle* h, int n_chains, double* d_out, hipStream_t s);
+// build.hip: E = Ks M, H = Cs + M^T E for D dense [N][N] components (H overwrites Cs)
+int magi_fused_operators(magi_handle* h, int N, int D, double* dCs_inout_H, const double* dM, const double* dKs, double* dE);
 int magi_launch_prepare(magi_handle* h, int n_chains, hipStream_t s);   // fills par from V_Q
 int magi_launch_tail(magi_handle* h, int n_chains, hipStream_t s);
 int magi_launch_init_chains(magi_handle* h, const long long* d_chain_ids, hipStream_t s);

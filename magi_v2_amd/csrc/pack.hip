@@ -60,7 +60,57 @@ int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double*
     hipLaunchKernelGGL(k_pack<PACK_SYM>, grid, block, 0, h->stream, dK_inv, h->dKsym, N, ld, mask, banded ? 1 : 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("pack launch: ") + hipGetErrorString(e));
-    MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+
+    // ---- single-phase operators of the sampler ----------------------------------------------------
+    //   t1 + t2 = xc^T FH xc - 2 f^T FE xc + f^T FK f,   FH = Csym + m^T Ksym m,  FE = Ksym m
+    // formed from the MASKED matrices, so the reference's band semantics carry over exactly: the
+    // products of band-b matrices have band <= 3b and are stored without truncation.
+    {
+        const bool fbanded = bandsize >= 0 && (6 * bandsize + 1) < N;
+        const int fW = fbanded ? 6 * bandsize + 1 : N;
+        const int ldf = (fW + 1) & ~1;
+        const size_t felems = (size_t)D * N * ldf;
+        if (felems != h->fused_elems || !h->dFH) {
+            if (h->dFH) (void)hipFree(h->dFH);
+            if (h->dFE) (void)hipFree(h->dFE);
+            if (h->dFEt) (void)hipFree(h->dFEt);
+            if (h->dFK) (void)hipFree(h->dFK);
+            h->dFH = h->dFE = h->dFEt = h->dFK = nullptr;
+            MAGI_HIP_CHECK(h, hipMalloc(&h->dFH, felems * sizeof(double)));
+            MAGI_HIP_CHECK(h, hipMalloc(&h->dFE, felems * sizeof(double)));
+            MAGI_HIP_CHECK(h, hipMalloc(&h->dFEt, felems * sizeof(double)));
+            MAGI_HIP_CHECK(h, hipMalloc(&h->dFK, felems * sizeof(double)));
+            h->fused_elems = felems;
+        }
+        const size_t nn = (size_t)D * N * N;
+        double *tCs = nullptr, *tM = nullptr, *tKs = nullptr, *tE = nullptr;
+        MAGI_HIP_CHECK(h, hipMalloc(&tCs, nn * sizeof(double)));
+        MAGI_HIP_CHECK(h, hipMalloc(&tM, nn * sizeof(double)));
+        MAGI_HIP_CHECK(h, hipMalloc(&tKs, nn * sizeof(double)));
+        MAGI_HIP_CHECK(h, hipMalloc(&tE, nn * sizeof(double)));
+        dim3 gd((N + 255) / 256, N, D);
+        hipLaunchKernelGGL(k_pack<PACK_SYM>, gd, block, 0, h->stream, dC_inv, tCs, N, N, mask, 0);
+        hipLaunchKernelGGL(k_pack<PACK_COPY>, gd, block, 0, h->stream, dM, tM, N, N, mask, 0);
+        hipLaunchKernelGGL(k_pack<PACK_SYM>, gd, block, 0, h->stream, dK_inv, tKs, N, N, mask, 0);
+        int rc = magi_fused_operators(h, N, D, tCs, tM, tKs, tE);
+        if (rc == MAGI_OK) {
+            const int fb = fbanded ? 3 * bandsize : -1;
+            dim3 gf((ldf + 255) / 256, N, D);
+            hipLaunchKernelGGL(k_pack<PACK_COPY>, gf, block, 0, h->stream, tCs, h->dFH, N, ldf, fb, fbanded ? 1 : 0);
+            hipLaunchKernelGGL(k_pack<PACK_COPY>, gf, block, 0, h->stream, tE, h->dFE, N, ldf, fb, fbanded ? 1 : 0);
+            hipLaunchKernelGGL(k_pack<PACK_TRANS>, gf, block, 0, h->stream, tE, h->dFEt, N, ldf, fb, fbanded ? 1 : 0);
+            hipLaunchKernelGGL(k_pack<PACK_COPY>, gf, block, 0, h->stream, tKs, h->dFK, N, ldf, fb, fbanded ? 1 : 0);
+            e = hipGetLastError();
+        }
+        hipError_t se = hipStreamSynchronize(h->stream);
+        (void)hipFree(tCs); (void)hipFree(tM); (void)hipFree(tKs); (void)hipFree(tE);
+        if (rc) return rc;
+        if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("fused pack launch: ") + hipGetErrorString(e));
+        if (se != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("fused pack: ") + hipGetErrorString(se));
+        pb.FH = h->dFH; pb.FE = h->dFE; pb.FEt = h->dFEt; pb.FK = h->dFK;
+        pb.ldf = ldf;
+        pb.bandf = fbanded ? 3 * bandsize : -1;
+    }
 
     pb.N = N;
     pb.D = D;

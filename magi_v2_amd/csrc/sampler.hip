@@ -7,14 +7,20 @@
 // U-turn test, max_tree_depth 10, max_energy_diff 1000; Nesterov dual averaging) is restated in
 // oracle/magi_oracle.py and mirrored here decision for decision, with a shared Philox4x32-10 RNG.
 //
-// MI355X design: a leapfrog is the static kernel sequence [phase1, phase2, phase3, tail].  The
-// tail (one 1024-thread workgroup per chain) finishes the gradient, completes the momentum
-// update, does all tree bookkeeping (multinomial proposal, checkpointed U-turn tests, doubling,
-// merge, transition end, dual averaging, temperature, next momentum draw) and writes the NEXT
-// position to evaluate.  No decision ever returns to the host, so the host only replays one
-// hipGraph of G leapfrog slots and polls a done counter; chains advance asynchronously, each
-// using every slot.  Energies follow TFP: energy = target - 0.5 p.p  (minus the Hamiltonian).
+// MI355X design: a leapfrog is the static kernel pair [single-phase mat-vecs, tail].  The tail
+// (one 512-thread workgroup per chain) assembles the gradient, completes the momentum update, does
+// all tree bookkeeping (multinomial proposal, checkpointed U-turn tests, doubling, merge,
+// transition end, dual averaging, temperature, next momentum draw) and writes the NEXT position
+// to evaluate.  No decision ever returns to the host, so the host only replays one hipGraph of
+// 32 leapfrog slots and polls a control block; chains advance asynchronously, each using every
+// slot.  Energies follow TFP: energy = target - 0.5 p.p  (minus the Hamiltonian).
+//
+// The tail runs ONCE per launch on one CU, i.e. on a cold instruction cache: its speed is set by
+// code size along the executed path.  Hence: one instantiation per drift (compile-time D, P),
+// every big helper has a single call site, fp64 transcendentals are noinline, and the rare
+// transition-end work sits behind one branch at the bottom.
 #include "magi_internal.h"
+#include "fused_pass.h"
 
 namespace {
 
@@ -22,7 +28,7 @@ struct TailVecs {
     double *q, *p, *g, *pL, *qL, *gL, *pR, *qR, *gR, *candq, *candg, *subq, *subg, *rho, *rhosub, *ckp, *ckrho;
 };
 
-__device__ inline TailVecs tail_vecs(const DevProblem& pb, double* vb) {
+__device__ __forceinline__ TailVecs tail_vecs(const DevProblem& pb, double* vb) {
     const size_t s = pb.dimp;
     TailVecs v;
     v.q = vb + V_Q * s; v.p = vb + V_P * s; v.g = vb + V_G * s;
@@ -35,109 +41,39 @@ __device__ inline TailVecs tail_vecs(const DevProblem& pb, double* vb) {
     return v;
 }
 
-// Scalar transcendental math is evaluated by ONE thread and broadcast through LDS: an fp64
-// exp/log is a ~100-instruction sequence, and 16 waves evaluating it redundantly cost tens of
-// microseconds per leapfrog (measured: 44 us tail -> see profiles/).
-struct Bcast {
-    double* s;   // LDS, >= 16 doubles
-};
-
-// Start a doubling from the end selected by the direction bit and take the first half/full step
-// (leapfrog with identity mass: p_half = p + eps/2 * grad ; q' = q + eps * p_half).
-__device__ inline void begin_doubling(const DevProblem& pb, const SamplerCfgDev& cfg, ChainCtl& c, const TailVecs& v, double* par) {
-    const int dim = pb.dim;
-    Philox4 r = philox4x32_10((unsigned)c.depth, (unsigned)c.k, (unsigned)c.chain_id, STREAM_DIRECTION, cfg.seed);
-    const bool fwd = (r.x & 1u) != 0;
-    c.dir = fwd ? 1 : -1;
-    const double* pe = fwd ? v.pR : v.pL;
-    const double* qe = fwd ? v.qR : v.qL;
-    const double* ge = fwd ? v.gR : v.gL;
-    const double bf = fwd ? c.bfacR : c.bfacL;
-    const double eps = c.dir * c.eps;
-    const double hs = 0.5 * eps * bf;
-    for (int e = threadIdx.x; e < dim; e += blockDim.x) {
-        const double ph = pe[e] + hs * ge[e];
-        v.p[e] = ph;
-        const double qn = qe[e] + eps * ph;
-        v.q[e] = qn;
-        v.rhosub[e] = 0.0;
-        if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par);
-    }
-    c.nsteps = 1 << c.depth;
-    c.it = 0;
-    c.sub_weight = -INFINITY;
-    c.e_sum_sub = 0.0;
-    c.sub_lf = 0;
-    c.cont = 1;
-    c.nd = c.not_div;
-    c.phase = PH_LEAF;
-}
-
-// Start transition k: temperature, momentum draw, both ends = current proposal, first doubling.
-__device__ inline void begin_sample(const DevProblem& pb, const SamplerCfgDev& cfg, ChainCtl& c, const TailVecs& v, double* par,
-                                    double* sh, double* shs) {
-    const int dim = pb.dim;
-    __syncthreads();
-    if (threadIdx.x == 0) shs[4] = cfg.anneal ? temperature(c.k, cfg.min_temp) : 1.0;
-    double pp[1] = {0.0};
-    for (int e = threadIdx.x; e < dim; e += blockDim.x) {
-        const double z = rng_normal_elem((unsigned)e, (unsigned)c.k, (unsigned)c.chain_id, cfg.seed);
-        pp[0] = fma(z, z, pp[0]);
-        v.pL[e] = z; v.pR[e] = z; v.rho[e] = z;
-        const double qq = v.candq[e], gg = v.candg[e];
-        v.qL[e] = qq; v.qR[e] = qq;
-        v.gL[e] = gg; v.gR[e] = gg;
-    }
-    block_sum<1>(pp, sh);              // (its barriers also publish shs[4])
-    c.beta_k = shs[4];
-    const double bc = cfg.stale ? c.beta_cache : c.beta_k;
-    c.eps = c.da_step_size;
-    c.init_energy = bc * c.cand_L - 0.5 * pp[0];
-    c.LL = c.LR = c.cand_L;
-    c.bfacL = c.bfacR = bc;
-    c.cand_bfac = bc;
-    c.cand_energy = c.init_energy;
-    c.cand_weight = 0.0;
-    c.e_sum = 0.0;
-    c.lf_count = 0;
-    c.not_div = 1;
-    c.is_accepted = 0;
-    c.depth = 0;
-    c.leaf_ctr = 0;
-    begin_doubling(pb, cfg, c, v, par);
-}
-
 // DualAveragingStepSizeAdaptation.one_step after the inner NUTS step (oracle: dual_averaging_update).
 // Evaluated by one thread; results returned through out[0..3].
-__device__ inline void dual_averaging_eval(const SamplerCfgDev& cfg, const ChainCtl& c, double e_sum, int lf_count, double* out) {
-    const double log_accept_ratio = log(e_sum / (double)lf_count);
+__device__ __noinline__ void dual_averaging_eval(double target_accept, int n_adapt, int prev, double da_step_size, double da_error_sum,
+                                                double da_log_avg, double da_log_shrink, double e_sum, int lf_count, double* out) {
+    const double log_accept_ratio = m_log(e_sum / (double)lf_count);
     double lap = isfinite(log_accept_ratio) ? log_accept_ratio : -INFINITY;
     lap = fmin(lap, 0.0);
-    const double accept = (lap > -INFINITY) ? exp(lap) : 0.0;
-    const int prev = c.da_step;
+    const double accept = (lap > -INFINITY) ? m_exp(lap) : 0.0;
     const double t = (double)(prev + 1);
-    double new_err = c.da_error_sum + cfg.target_accept - accept;
+    double new_err = da_error_sum + target_accept - accept;
     const double soft_t = 10.0 + t;                              // step_count_smoothing
-    const double new_log_step = c.da_log_shrink - (new_err * sqrt(t)) / (soft_t * 0.05);   // exploration_shrinkage
+    const double new_log_step = da_log_shrink - (new_err * sqrt(t)) / (soft_t * 0.05);   // exploration_shrinkage
     const double eta = pow(t, -0.75);                            // decay_rate
-    double new_log_avg = eta * new_log_step + (1.0 - eta) * c.da_log_avg;
+    double new_log_avg = eta * new_log_step + (1.0 - eta) * da_log_avg;
     double new_ss;
-    if (prev < cfg.n_adapt) new_ss = exp(new_log_step);
-    else if (prev > cfg.n_adapt) new_ss = c.da_step_size;
-    else new_ss = exp(new_log_avg);
-    if (prev > cfg.n_adapt) { new_err = c.da_error_sum; new_log_avg = c.da_log_avg; }
+    if (prev < n_adapt) new_ss = m_exp(new_log_step);
+    else if (prev > n_adapt) new_ss = da_step_size;
+    else new_ss = m_exp(new_log_avg);
+    if (prev > n_adapt) { new_err = da_error_sum; new_log_avg = da_log_avg; }
     out[0] = log_accept_ratio;
     out[1] = new_ss;
     out[2] = new_err;
     out[3] = new_log_avg;
 }
 
+template <int DRIFT>
 __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevChains ch, SamplerCfgDev cfg) {
-    __shared__ double sh[(3 + MAGI_MAX_D + MAGI_MAX_P) * 16];
+    __shared__ double sh[(FP_KMAX + 1) * 16];
     __shared__ double shs[16];
     if (ch.gctl->all_done) return;
     const int chain = blockIdx.x;
     const int tid = threadIdx.x;
+    MAGI_STAMP(ch.par + (size_t)chain * PAR_COUNT, 0);
     ChainCtl c = ch.ctl[chain];
     const int dim = pb.dim;
     const int stop_k = min(ch.gctl->stop_k, cfg.total);
@@ -146,197 +82,256 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
     double* par = ch.par + (size_t)chain * PAR_COUNT;
     const TailVecs v = tail_vecs(pb, vb);
 
+    bool do_sample = false, do_doubling = false;     // what to set up before returning
+
     if (c.phase == PH_IDLE) {
-        if (c.k < stop_k) {            // resumed by a later magi_sampler_run
-            begin_sample(pb, cfg, c, v, par, sh, shs);
-            if (tid == 0) ch.ctl[chain] = c;
-        } else if (c.done_epoch != epoch) {
-            c.done_epoch = epoch;
-            if (tid == 0) {
-                ch.ctl[chain] = c;
-                const int done = atomicAdd(&ch.gctl->done_chains, 1) + 1;
-                if (done >= ch.gctl->n_chains) ch.gctl->all_done = 1;
+        if (c.k < stop_k) {
+            do_sample = true;                        // resumed by a later magi_sampler_run
+        } else {
+            if (c.done_epoch != epoch) {
+                c.done_epoch = epoch;
+                if (tid == 0) {
+                    ch.ctl[chain] = c;
+                    const int done = atomicAdd(&ch.gctl->done_chains, 1) + 1;
+                    if (done >= ch.gctl->n_chains) ch.gctl->all_done = 1;
+                }
             }
-        }
-        return;
-    }
-
-    // data-independent uniforms of this leaf / a possible merge: drawn early by two idle waves
-    if (c.phase == PH_LEAF) {
-        if (tid == 64) shs[8] = log1p(-rng_uniform((unsigned)c.leaf_ctr, (unsigned)c.k, (unsigned)c.chain_id, STREAM_LEAF, cfg.seed));
-        if (tid == 128) shs[9] = log1p(-rng_uniform((unsigned)c.depth, (unsigned)c.k, (unsigned)c.chain_id, STREAM_MERGE, cfg.seed));
-    }
-
-    // ---- 1. finish the gradient at V_Q ---------------------------------------------------------
-    const FinalizeOut fo = finalize_gradient(pb, vb, par, sh, shs);
-    const double L = fo.L;
-
-    if (c.phase == PH_INIT) {
-        // bootstrap_results: target / gradient at the initial state, cached at beta_temp(0)
-        for (int e = tid; e < dim; e += blockDim.x) { v.candq[e] = v.q[e]; v.candg[e] = v.g[e]; }
-        if (tid == 0) shs[5] = cfg.anneal ? temperature(0, cfg.min_temp) : 1.0;
-        __syncthreads();
-        c.cand_L = L;
-        c.beta_cache = shs[5];
-        if (c.k < stop_k) begin_sample(pb, cfg, c, v, par, sh, shs);
-        else c.phase = PH_IDLE;
-        if (tid == 0) ch.ctl[chain] = c;
-        return;
-    }
-
-    // ---- 2. leaf: complete the momentum update, sums, checkpoints -------------------------------
-    c.L_cur = L;
-    c.total_leapfrogs += 1;
-    const double eps = c.dir * c.eps;
-    const double hs = 0.5 * eps * c.beta_k;
-    const int it = c.it;
-    const bool even = (it & 1) == 0;
-    double* ckp_w = v.ckp + (size_t)__popc((unsigned)it) * pb.dimp;
-    double* ckr_w = v.ckrho + (size_t)__popc((unsigned)it) * pb.dimp;
-    double pp[1] = {0.0};
-    for (int e = tid; e < dim; e += blockDim.x) {
-        const double pn = v.p[e] + hs * v.g[e];
-        v.p[e] = pn;
-        const double rs = v.rhosub[e] + pn;
-        v.rhosub[e] = rs;
-        pp[0] = fma(pn, pn, pp[0]);
-        if (even) { ckp_w[e] = pn; ckr_w[e] = rs; }
-    }
-    block_sum<1>(pp, sh);
-
-    bool no_u = true;
-    if (!even) {
-        for (int kk = 1; ((it + 1) & ((1 << kk) - 1)) == 0 && (1 << kk) <= c.nsteps; ++kk) {
-            const int left = it + 1 - (1 << kk);
-            const double* cp = v.ckp + (size_t)__popc((unsigned)left) * pb.dimp;
-            const double* cr = v.ckrho + (size_t)__popc((unsigned)left) * pb.dimp;
-            double dots[2] = {0.0, 0.0};
-            for (int e = tid; e < dim; e += blockDim.x) {
-                const double df = v.rhosub[e] - cr[e];
-                dots[0] = fma(df, cp[e], dots[0]);
-                dots[1] = fma(df, v.p[e], dots[1]);
-            }
-            block_sum<2>(dots, sh);
-            no_u = no_u && (dots[0] > 0.0) && (dots[1] > 0.0);
-        }
-    }
-
-    // ---- 3. energy, multinomial proposal inside the subtree -----------------------------------------
-    double energy = c.beta_k * L - 0.5 * pp[0];
-    if (isnan(energy)) energy = -INFINITY;
-    const double ediff = energy - c.init_energy;
-    const bool not_divergent = (-ediff < cfg.max_energy_diff);
-    if (tid == 0) shs[10] = logaddexp(c.sub_weight, ediff);
-    if (tid == 192) shs[11] = exp(fmin(ediff, 0.0));
-    __syncthreads();
-    {
-        const double wsum = shs[10];
-        const double thresh = ediff - wsum;
-        const double u = shs[8];
-        c.leaf_ctr += 1;
-        if (u <= thresh) {
-            for (int e = tid; e < dim; e += blockDim.x) { v.subq[e] = v.q[e]; v.subg[e] = v.g[e]; }
-            c.sub_L = L;
-            c.sub_energy = energy;
-        }
-        c.sub_weight = wsum;
-    }
-    const bool cont_tree = not_divergent && (c.cont != 0);
-    c.cont = (no_u && cont_tree) ? 1 : 0;
-    c.nd = (c.nd && not_divergent) ? 1 : 0;
-    if (cont_tree) c.e_sum_sub += shs[11];
-    c.sub_lf += 1;
-    c.it = it + 1;
-
-    if (c.it < c.nsteps && c.cont) {
-        // ---- 4a. next leaf of the same subtree: half step + position update -----------------------
-        for (int e = tid; e < dim; e += blockDim.x) {
-            const double ph = v.p[e] + hs * v.g[e];
-            v.p[e] = ph;
-            const double qn = v.q[e] + eps * ph;
-            v.q[e] = qn;
-            if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par);
-        }
-        if (tid == 0) ch.ctl[chain] = c;
-        return;
-    }
-
-    // ---- 4b. subtree finished: merge into the trajectory (biased progressive sampling) --------------
-    const double tree_weight = c.cont ? c.sub_weight : -INFINITY;
-    __syncthreads();
-    if (tid == 0) shs[12] = logaddexp(tree_weight, c.cand_weight);
-    {
-        const double thresh = tree_weight - c.cand_weight;
-        const double u = shs[9];
-        const bool choose = (u <= thresh) && (c.cont != 0);
-        double* pe = (c.dir > 0) ? v.pR : v.pL;
-        double* qe = (c.dir > 0) ? v.qR : v.qL;
-        double* ge = (c.dir > 0) ? v.gR : v.gL;
-        const double* po = (c.dir > 0) ? v.pL : v.pR;    // the other end
-        double dots[2] = {0.0, 0.0};
-        for (int e = tid; e < dim; e += blockDim.x) {
-            if (choose) { v.candq[e] = v.subq[e]; v.candg[e] = v.subg[e]; }
-            const double pn = v.p[e];
-            pe[e] = pn; qe[e] = v.q[e]; ge[e] = v.g[e];
-            const double rr = v.rho[e] + v.rhosub[e];
-            v.rho[e] = rr;
-            dots[0] = fma(rr, po[e], dots[0]);
-            dots[1] = fma(rr, pn, dots[1]);
-        }
-        block_sum<2>(dots, sh);        // (barriers publish shs[12])
-        if (choose) { c.cand_L = c.sub_L; c.cand_energy = c.sub_energy; c.cand_bfac = c.beta_k; c.is_accepted = 1; }
-        c.cand_weight = shs[12];
-        if (c.dir > 0) { c.LR = c.L_cur; c.bfacR = c.beta_k; } else { c.LL = c.L_cur; c.bfacL = c.beta_k; }
-        const bool no_u_traj = (dots[0] > 0.0) && (dots[1] > 0.0);
-        c.e_sum += c.e_sum_sub;
-        c.lf_count += c.sub_lf;
-        c.not_div = c.nd;
-        c.depth += 1;
-        const bool continue_tree = (c.cont != 0) && no_u_traj;
-        if (c.depth < cfg.max_depth && continue_tree) {
-            begin_doubling(pb, cfg, c, v, par);
-            if (tid == 0) ch.ctl[chain] = c;
             return;
         }
+    } else {
+        // ---- gradient at V_Q (+ for a leaf: momentum half step, sums, checkpoint, two U-turn tests) -----
+        const bool leaf = (c.phase == PH_LEAF);
+        MAGI_STAMP(par, 1);
+        if (leaf) {
+            // data-independent uniforms of this leaf / a possible merge: drawn by two otherwise idle waves
+            if (tid == 64) shs[8] = m_log1p(-rng_uniform((unsigned)c.leaf_ctr, (unsigned)c.k, (unsigned)c.chain_id, STREAM_LEAF, cfg.seed));
+            if (tid == 128) shs[9] = m_log1p(-rng_uniform((unsigned)c.depth, (unsigned)c.k, (unsigned)c.chain_id, STREAM_MERGE, cfg.seed));
+        } else if (tid == 64) {
+            shs[8] = cfg.anneal ? temperature(0, cfg.min_temp) : 1.0;
+        }
+        const double eps = c.dir * c.eps;
+        const double hs = 0.5 * eps * c.beta_k;
+        const int it = c.it;
+        const bool even = (it & 1) == 0;
+        int nk = 0;                              // U-turn checks due at this leaf (balanced sub-subtrees closing here)
+        if (leaf && !even)
+            for (int kk = 1; ((it + 1) & ((1 << kk) - 1)) == 0 && (1 << kk) <= c.nsteps; ++kk) nk = kk;
+        LeafArgs la;
+        la.leaf = leaf;
+        la.hs = hs;
+        la.even = even;
+        la.ckp_w = v.ckp + (size_t)__popc((unsigned)it) * pb.dimp;
+        la.ckr_w = v.ckrho + (size_t)__popc((unsigned)it) * pb.dimp;
+        la.nchk = min(nk, 2);
+        if (nk >= 1) { const int s1 = __popc((unsigned)(it + 1 - 2)); la.cp1 = v.ckp + (size_t)s1 * pb.dimp; la.cr1 = v.ckrho + (size_t)s1 * pb.dimp; }
+        if (nk >= 2) { const int s2 = __popc((unsigned)(it + 1 - 4)); la.cp2 = v.ckp + (size_t)s2 * pb.dimp; la.cr2 = v.ckrho + (size_t)s2 * pb.dimp; }
 
-        // ---- 5. transition finished -----------------------------------------------------------------
-        if (tid == 0) dual_averaging_eval(cfg, c, c.e_sum, c.lf_count, &shs[0]);
+        const PassOut po = fused_pass<DRIFT>(pb, vb, par, sh, shs, la);
+        MAGI_STAMP(par, 4);
+        const double L = po.L;
+
+        if (!leaf) {
+            // bootstrap_results: target / gradient at the initial state, cached at beta_temp(0)
+            for (int e = tid; e < dim; e += blockDim.x) { v.candq[e] = v.q[e]; v.candg[e] = v.g[e]; }
+            c.cand_L = L;
+            c.beta_cache = shs[8];
+            if (c.k < stop_k) do_sample = true;
+            else c.phase = PH_IDLE;
+        } else {
+            c.L_cur = L;
+            c.total_leapfrogs += 1;
+            bool no_u = true;
+            if (nk >= 1) no_u = no_u && (po.dA1 > 0.0) && (po.dB1 > 0.0);
+            if (nk >= 2) no_u = no_u && (po.dA2 > 0.0) && (po.dB2 > 0.0);
+            for (int kk = 3; kk <= nk; ++kk) {       // one leaf in eight gets here
+                const int left = it + 1 - (1 << kk);
+                const double* cp = v.ckp + (size_t)__popc((unsigned)left) * pb.dimp;
+                const double* cr = v.ckrho + (size_t)__popc((unsigned)left) * pb.dimp;
+                double dots[2] = {0.0, 0.0};
+                for (int e = tid; e < dim; e += blockDim.x) {
+                    const double df = v.rhosub[e] - cr[e];
+                    dots[0] = fma(df, cp[e], dots[0]);
+                    dots[1] = fma(df, v.p[e], dots[1]);
+                }
+                block_sum<2>(dots, sh);
+                no_u = no_u && (dots[0] > 0.0) && (dots[1] > 0.0);
+            }
+
+            // ---- energy, multinomial proposal inside the subtree --------------------------------------
+            double energy = c.beta_k * L - 0.5 * po.pp;
+            if (isnan(energy)) energy = -INFINITY;
+            const double ediff = energy - c.init_energy;
+            const bool not_divergent = (-ediff < cfg.max_energy_diff);
+            if (tid == 0) shs[10] = logaddexp(c.sub_weight, ediff);
+            if (tid == 192) shs[11] = m_exp(fmin(ediff, 0.0));
+            __syncthreads();
+            MAGI_STAMP(par, 5);
+            const double wsum_leaf = shs[10];
+            const bool accept_leaf = (shs[8] <= ediff - wsum_leaf);
+            c.leaf_ctr += 1;
+            if (accept_leaf) { c.sub_L = L; c.sub_energy = energy; }
+            c.sub_weight = wsum_leaf;
+            const bool cont_tree = not_divergent && (c.cont != 0);
+            c.cont = (no_u && cont_tree) ? 1 : 0;
+            c.nd = (c.nd && not_divergent) ? 1 : 0;
+            if (cont_tree) c.e_sum_sub += shs[11];
+            c.sub_lf += 1;
+            c.it = it + 1;
+
+            if (c.it < c.nsteps && c.cont) {
+                // ---- proposal copy + next leaf of the same subtree (half step + position): one sweep -----
+                for (int e = tid; e < dim; e += blockDim.x) {
+                    const double qv = v.q[e], gv = v.g[e];
+                    if (accept_leaf) { v.subq[e] = qv; v.subg[e] = gv; }
+                    const double ph = v.p[e] + hs * gv;
+                    v.p[e] = ph;
+                    const double qn = qv + eps * ph;
+                    v.q[e] = qn;
+                    if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par);
+                }
+                MAGI_STAMP(par, 6);
+                if (tid == 0) ch.ctl[chain] = c;
+                return;
+            }
+
+            // ---- subtree finished: merge into the trajectory (biased progressive sampling) ---------------
+            const double tree_weight = c.cont ? c.sub_weight : -INFINITY;
+            if (tid == 0) shs[12] = logaddexp(tree_weight, c.cand_weight);
+            const double thresh = tree_weight - c.cand_weight;
+            const bool choose = (shs[9] <= thresh) && (c.cont != 0);
+            double* pe = (c.dir > 0) ? v.pR : v.pL;
+            double* qe = (c.dir > 0) ? v.qR : v.qL;
+            double* ge = (c.dir > 0) ? v.gR : v.gL;
+            const double* po_ = (c.dir > 0) ? v.pL : v.pR;    // the other end
+            double dots[2] = {0.0, 0.0};
+            for (int e = tid; e < dim; e += blockDim.x) {
+                const double qv = v.q[e], gv = v.g[e];
+                // the subtree proposal is this leaf if it was just accepted, else what V_SUB holds
+                const double sq = accept_leaf ? qv : v.subq[e], sg = accept_leaf ? gv : v.subg[e];
+                if (choose) { v.candq[e] = sq; v.candg[e] = sg; }
+                const double pn = v.p[e];
+                pe[e] = pn; qe[e] = qv; ge[e] = gv;
+                const double rr = v.rho[e] + v.rhosub[e];
+                v.rho[e] = rr;
+                dots[0] = fma(rr, po_[e], dots[0]);
+                dots[1] = fma(rr, pn, dots[1]);
+            }
+            block_sum<2>(dots, sh);        // (its barriers publish shs[12])
+            if (choose) { c.cand_L = c.sub_L; c.cand_energy = c.sub_energy; c.cand_bfac = c.beta_k; c.is_accepted = 1; }
+            c.cand_weight = shs[12];
+            if (c.dir > 0) { c.LR = c.L_cur; c.bfacR = c.beta_k; } else { c.LL = c.L_cur; c.bfacL = c.beta_k; }
+            const bool no_u_traj = (dots[0] > 0.0) && (dots[1] > 0.0);
+            c.e_sum += c.e_sum_sub;
+            c.lf_count += c.sub_lf;
+            c.not_div = c.nd;
+            c.depth += 1;
+            const bool continue_tree = (c.cont != 0) && no_u_traj;
+            if (c.depth < cfg.max_depth && continue_tree) {
+                do_doubling = true;
+            } else {
+                // ---- transition finished ------------------------------------------------------------------
+                if (tid == 0)
+                    dual_averaging_eval(cfg.target_accept, cfg.n_adapt, c.da_step, c.da_step_size, c.da_error_sum, c.da_log_avg,
+                                        c.da_log_shrink, c.e_sum, c.lf_count, &shs[0]);
+                __syncthreads();
+                const int k = c.k;
+                if (tid == 0) {
+                    const size_t o = (size_t)chain * cfg.total + k;
+                    ch.d_step_size[o] = c.eps;
+                    ch.d_lar[o] = shs[0];
+                    ch.d_target[o] = c.cand_bfac * c.cand_L;
+                    ch.d_energy[o] = c.cand_energy;
+                    ch.d_beta[o] = c.beta_k;
+                    ch.d_leapfrogs[o] = c.lf_count;
+                    ch.d_depth[o] = c.depth;
+                    ch.d_flags[o] = (c.not_div ? 0 : 1) | (continue_tree ? 2 : 0) | (c.is_accepted ? 4 : 0);
+                }
+                if (k >= cfg.burnin) {
+                    double* out = ch.samples + ((size_t)chain * (cfg.total - cfg.burnin) + (k - cfg.burnin)) * pb.dimp;
+                    for (int e = tid; e < dim; e += blockDim.x) out[e] = v.candq[e];
+                }
+                if (c.is_accepted) c.beta_cache = c.beta_k;
+                c.da_step_size = shs[1];
+                c.da_error_sum = shs[2];
+                c.da_log_avg = shs[3];
+                c.da_step += 1;
+                c.k = k + 1;
+                if (c.k >= stop_k) {
+                    c.phase = PH_IDLE;
+                    c.done_epoch = epoch;
+                    if (tid == 0) {
+                        ch.ctl[chain] = c;
+                        const int done = atomicAdd(&ch.gctl->done_chains, 1) + 1;
+                        if (done >= ch.gctl->n_chains) ch.gctl->all_done = 1;
+                    }
+                    return;
+                }
+                do_sample = true;
+            }
+        }
+    }
+
+    if (do_sample) {
+        // ---- start transition k: temperature, momentum draw, both ends = current proposal ----------------
         __syncthreads();
-        const double lar = shs[0];
-        const int k = c.k;
-        if (tid == 0) {
-            const size_t o = (size_t)chain * cfg.total + k;
-            ch.d_step_size[o] = c.eps;
-            ch.d_lar[o] = lar;
-            ch.d_target[o] = c.cand_bfac * c.cand_L;
-            ch.d_energy[o] = c.cand_energy;
-            ch.d_beta[o] = c.beta_k;
-            ch.d_leapfrogs[o] = c.lf_count;
-            ch.d_depth[o] = c.depth;
-            ch.d_flags[o] = (c.not_div ? 0 : 1) | (continue_tree ? 2 : 0) | (c.is_accepted ? 4 : 0);
+        if (tid == 0) shs[4] = cfg.anneal ? temperature(c.k, cfg.min_temp) : 1.0;
+        double pp0[1] = {0.0};
+        for (int e = tid; e < dim; e += blockDim.x) {
+            const double z = rng_normal_elem((unsigned)e, (unsigned)c.k, (unsigned)c.chain_id, cfg.seed);
+            pp0[0] = fma(z, z, pp0[0]);
+            v.pL[e] = z; v.pR[e] = z; v.rho[e] = z;
+            const double qq = v.candq[e], gg = v.candg[e];
+            v.qL[e] = qq; v.qR[e] = qq;
+            v.gL[e] = gg; v.gR[e] = gg;
         }
-        if (k >= cfg.burnin) {
-            double* out = ch.samples + ((size_t)chain * (cfg.total - cfg.burnin) + (k - cfg.burnin)) * pb.dimp;
-            for (int e = tid; e < dim; e += blockDim.x) out[e] = v.candq[e];
-        }
-        if (c.is_accepted) c.beta_cache = c.beta_k;
-        c.da_step_size = shs[1];
-        c.da_error_sum = shs[2];
-        c.da_log_avg = shs[3];
-        c.da_step += 1;
-        c.k = k + 1;
+        block_sum<1>(pp0, sh);              // (its barriers also publish shs[4])
+        c.beta_k = shs[4];
+        const double bc = cfg.stale ? c.beta_cache : c.beta_k;
+        c.eps = c.da_step_size;
+        c.init_energy = bc * c.cand_L - 0.5 * pp0[0];
+        c.LL = c.LR = c.cand_L;
+        c.bfacL = c.bfacR = bc;
+        c.cand_bfac = bc;
+        c.cand_energy = c.init_energy;
+        c.cand_weight = 0.0;
+        c.e_sum = 0.0;
+        c.lf_count = 0;
+        c.not_div = 1;
+        c.is_accepted = 0;
+        c.depth = 0;
+        c.leaf_ctr = 0;
+        do_doubling = true;
     }
-    if (c.k >= stop_k) {
-        c.phase = PH_IDLE;
-        c.done_epoch = epoch;
-        if (tid == 0) {
-            ch.ctl[chain] = c;
-            const int done = atomicAdd(&ch.gctl->done_chains, 1) + 1;
-            if (done >= ch.gctl->n_chains) ch.gctl->all_done = 1;
+
+    if (do_doubling) {
+        // ---- start a doubling from the end selected by the direction bit; first half/full step ----------
+        // (leapfrog with identity mass: p_half = p + eps/2 * grad ; q' = q + eps * p_half)
+        Philox4 r = philox4x32_10((unsigned)c.depth, (unsigned)c.k, (unsigned)c.chain_id, STREAM_DIRECTION, cfg.seed);
+        const bool fwd = (r.x & 1u) != 0;
+        c.dir = fwd ? 1 : -1;
+        const double* pe = fwd ? v.pR : v.pL;
+        const double* qe = fwd ? v.qR : v.qL;
+        const double* ge = fwd ? v.gR : v.gL;
+        const double bf = fwd ? c.bfacR : c.bfacL;
+        const double eps = c.dir * c.eps;
+        const double hs = 0.5 * eps * bf;
+        for (int e = tid; e < dim; e += blockDim.x) {
+            const double ph = pe[e] + hs * ge[e];
+            v.p[e] = ph;
+            const double qn = qe[e] + eps * ph;
+            v.q[e] = qn;
+            v.rhosub[e] = 0.0;
+            if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par);
         }
-        return;
+        c.nsteps = 1 << c.depth;
+        c.it = 0;
+        c.sub_weight = -INFINITY;
+        c.e_sum_sub = 0.0;
+        c.sub_lf = 0;
+        c.cont = 1;
+        c.nd = c.not_div;
+        c.phase = PH_LEAF;
     }
-    begin_sample(pb, cfg, c, v, par, sh, shs);
     if (tid == 0) ch.ctl[chain] = c;
 }
 
@@ -363,7 +358,12 @@ __global__ void k_init_chains(DevChains ch, SamplerCfgDev cfg, const long long* 
 }  // namespace
 
 int magi_launch_tail(magi_handle* h, int n_chains, hipStream_t s) {
-    hipLaunchKernelGGL(k_tail, dim3(n_chains), dim3(MAGI_TAIL_THREADS), 0, s, h->pb, h->ch, h->cfg);
+    const dim3 g(n_chains), b(MAGI_TAIL_THREADS);
+    switch (h->pb.drift) {
+    case MAGI_DRIFT_SEIR3: hipLaunchKernelGGL(k_tail<MAGI_DRIFT_SEIR3>, g, b, 0, s, h->pb, h->ch, h->cfg); break;
+    case MAGI_DRIFT_SEIR4: hipLaunchKernelGGL(k_tail<MAGI_DRIFT_SEIR4>, g, b, 0, s, h->pb, h->ch, h->cfg); break;
+    default: hipLaunchKernelGGL(k_tail<MAGI_DRIFT_SIRW>, g, b, 0, s, h->pb, h->ch, h->cfg); break;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("tail launch: ") + hipGetErrorString(e));
     return MAGI_OK;

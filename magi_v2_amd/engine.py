@@ -47,6 +47,7 @@ _SYMBOLS = {
     "magi_set_matrices": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]),
     "magi_set_problem": (C.c_int, [C.c_void_p, _dp, _dp, _lp, _dp, C.c_int64, C.c_double, _dp, C.c_int, C.c_int]),
     "magi_logpost_grad": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp]),
+    "magi_logpost_grad_fused": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp]),
     "magi_sampler_cfg_default": (None, [C.POINTER(SamplerCfg)]),
     "magi_sampler_init": (C.c_int, [C.c_void_p, C.POINTER(SamplerCfg), C.c_int, _dp, _dp, _dp, C.c_uint64, _lp]),
     "magi_sampler_run": (C.c_int, [C.c_void_p, C.c_int, _lp, _dp]),
@@ -57,6 +58,7 @@ _SYMBOLS = {
     "magi_sample": (C.c_int, [C.c_void_p, C.POINTER(SamplerCfg), C.c_int, _dp, _dp, _dp, C.c_uint64, _lp, _dp, _dp, _dp]),
     "magi_time_gradient": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp]),
     "magi_gradient_bytes": (C.c_int, [C.c_void_p, C.c_int, _dp]),
+    "magi_debug_par": (C.c_int, [C.c_void_p, C.c_int, _dp]),
 }
 
 _lib = None
@@ -190,14 +192,16 @@ class MagiEngine:
         X = _f64(X, (n, self.N, self.D))
         return n, X, _f64(sig_pre, (n, self.D)), _f64(th_pre, (n, self.P))
 
-    def logpost_grad(self, X, sig_pre, th_pre, beta_temp=1.0, want_terms=False):
-        """unnormalized_log_prob (magi_v2.py:308-348) + gradient for one state or a batch of states."""
+    def logpost_grad(self, X, sig_pre, th_pre, beta_temp=1.0, want_terms=False, fused=False):
+        """unnormalized_log_prob (magi_v2.py:308-348) + gradient for one state or a batch of states.
+        fused=True evaluates it through the sampler's single-phase kernels instead."""
         single = np.asarray(X).ndim == 2
         n, X, sp, tp = self._states(X, sig_pre, th_pre)
         logp, gX = np.empty(n), np.empty((n, self.N, self.D))
         gs, gt, terms = np.empty((n, self.D)), np.empty((n, self.P)), np.empty((n, 4))
-        self._check(self._lib.magi_logpost_grad(self._h, n, _ptr(X), _ptr(sp), _ptr(tp), float(beta_temp), _ptr(logp),
-                                                _ptr(gX), _ptr(gs), _ptr(gt), _ptr(terms)))
+        fn = self._lib.magi_logpost_grad_fused if fused else self._lib.magi_logpost_grad
+        self._check(fn(self._h, n, _ptr(X), _ptr(sp), _ptr(tp), float(beta_temp), _ptr(logp),
+                       _ptr(gX), _ptr(gs), _ptr(gt), _ptr(terms)))
         out = (logp[0], gX[0], gs[0], gt[0]) if single else (logp, gX, gs, gt)
         if want_terms:
             out = out + ((terms[0] if single else terms),)
@@ -267,11 +271,16 @@ class MagiEngine:
     # -- instrumentation ------------------------------------------------------------------------
     def time_gradient(self, n_chains=1, reps=50):
         total = C.c_double(0.0)
-        ph = np.zeros(4)
+        ph = np.zeros(6)
         self._check(self._lib.magi_time_gradient(self._h, int(n_chains), int(reps), C.byref(total), _ptr(ph)))
         return total.value, ph
 
+    def debug_par(self, chain=0):
+        out = np.zeros(64)
+        self._check(self._lib.magi_debug_par(self._h, int(chain), _ptr(out)))
+        return out
+
     def gradient_bytes(self, n_chains=1):
-        b = np.zeros(4)
+        b = np.zeros(6)
         self._check(self._lib.magi_gradient_bytes(self._h, int(n_chains), _ptr(b)))
         return b
