@@ -31,7 +31,7 @@ void free_matrices(magi_handle* h) {
 
 void free_chains(magi_handle* h) {
     DevChains& c = h->ch;
-    free_dev(c.vec); free_dev(c.ctl); free_dev(c.par); free_dev(c.gctl); free_dev(c.samples);
+    free_dev(c.vec); free_dev(c.ctl); free_dev(c.par); free_dev(c.plan); free_dev(c.part); free_dev(c.gctl); free_dev(c.samples);
     free_dev(c.d_step_size); free_dev(c.d_lar); free_dev(c.d_target); free_dev(c.d_energy); free_dev(c.d_beta);
     free_dev(c.d_leapfrogs); free_dev(c.d_depth); free_dev(c.d_flags);
     free_dev(h->d_chain_ids); free_dev(h->d_fin);
@@ -81,7 +81,7 @@ int build_graph(magi_handle* h) {
     MAGI_HIP_CHECK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     int rc = MAGI_OK;
     for (int s = 0; s < kGraphSlots && rc == MAGI_OK; ++s) {
-        rc = magi_launch_fused(h, h->n_chains, h->stream);
+        rc = magi_launch_leap(h, h->n_chains, h->stream);
         if (rc == MAGI_OK) rc = magi_launch_tail(h, h->n_chains, h->stream);
     }
     hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
@@ -107,6 +107,11 @@ int magi_ensure_chains(magi_handle* h, int n) {
         MAGI_HIP_CHECK(h, hipMemset(h->ch.ctl, 0, sizeof(ChainCtl) * n));
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.par, sizeof(double) * PAR_COUNT * n));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.par, 0, sizeof(double) * PAR_COUNT * n));
+        MAGI_HIP_CHECK(h, hipMalloc(&h->ch.plan, sizeof(LeafPlan) * n));
+        MAGI_HIP_CHECK(h, hipMemset(h->ch.plan, 0, sizeof(LeafPlan) * n));
+        h->ch.n_wg = magi_leap_wgs(h->pb);
+        MAGI_HIP_CHECK(h, hipMalloc(&h->ch.part, sizeof(double) * PART_K * h->ch.n_wg * n));
+        MAGI_HIP_CHECK(h, hipMemset(h->ch.part, 0, sizeof(double) * PART_K * h->ch.n_wg * n));
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.gctl, sizeof(GlobalCtl)));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.gctl, 0, sizeof(GlobalCtl)));
         MAGI_HIP_CHECK(h, hipMalloc(&h->d_chain_ids, sizeof(long long) * n));
@@ -265,8 +270,9 @@ static int logpost_grad_impl(magi_handle* h, bool fused, int n_chains, const dou
     MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.gctl, 0, sizeof(GlobalCtl), h->stream));
     if ((rc = magi_launch_prepare(h, n_chains, h->stream))) return rc;
     if (fused) {
-        if ((rc = magi_launch_fused(h, n_chains, h->stream))) return rc;
-        if ((rc = magi_launch_finalize_fused(h, n_chains, h->d_fin, h->stream))) return rc;
+        if ((rc = magi_launch_plan_eval(h, n_chains, h->stream))) return rc;
+        if ((rc = magi_launch_leap(h, n_chains, h->stream))) return rc;
+        if ((rc = magi_launch_leap_finalize(h, n_chains, h->d_fin, h->stream))) return rc;
     } else {
         if ((rc = magi_launch_gradient(h, n_chains, h->stream))) return rc;
         if ((rc = magi_launch_finalize(h, n_chains, h->d_fin, h->stream))) return rc;
@@ -374,7 +380,7 @@ int magi_sampler_init(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains,
     if ((rc = magi_launch_init_chains(h, h->d_chain_ids, h->stream))) return rc;
     // bootstrap_results: one gradient at the initial state (the tail stores it as the proposal)
     if ((rc = magi_launch_prepare(h, n_chains, h->stream))) return rc;
-    if ((rc = magi_launch_fused(h, n_chains, h->stream))) return rc;
+    if ((rc = magi_launch_leap(h, n_chains, h->stream))) return rc;
     if ((rc = magi_launch_tail(h, n_chains, h->stream))) return rc;
     MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     h->epoch = 0;
@@ -431,7 +437,7 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
                 MAGI_HIP_CHECK(h, hipGraphLaunch(h->graph_exec, h->stream));
             } else {
                 for (int sl = 0; sl < kGraphSlots; ++sl) {
-                    if ((rc = magi_launch_fused(h, h->n_chains, h->stream))) return rc;
+                    if ((rc = magi_launch_leap(h, h->n_chains, h->stream))) return rc;
                     if ((rc = magi_launch_tail(h, h->n_chains, h->stream))) return rc;
                 }
             }
@@ -552,8 +558,8 @@ int magi_gradient_bytes(magi_handle* h, int n_chains, double* phase_bytes) {
     phase_bytes[2] = 1.0 * mat + 5.0 * vec;   // Mt      ; read Kr, X, Cx, yobs, write gX
     phase_bytes[3] = 5.0 * vec;               // reduce  ; read X, Cx, r, Kr, yobs
     const double Wf = pb.bandf < 0 ? (double)pb.N : (double)(2 * pb.bandf + 1);
-    phase_bytes[4] = 4.0 * (double)pb.D * pb.N * Wf * 8.0 + 5.0 * vec;   // fused: FH, FE, FEt, FK ; read X, write 4 vectors
-    phase_bytes[5] = 9.0 * vec;               // fused reduce: X, 4 vectors, yobs, p, rho, write g
+    phase_bytes[4] = 4.0 * (double)pb.D * pb.N * Wf * 8.0 + 8.0 * vec;   // leap: FH, FE, FEt, FK ; X, yobs, p, rho ; g, p_leaf, p', x'
+    phase_bytes[5] = (double)n_chains * magi_leap_wgs(pb) * PART_K * 8.0; // tail: the workgroup partials
     return MAGI_OK;
 }
 
@@ -565,6 +571,8 @@ int magi_time_gradient(magi_handle* h, int n_chains, int reps, double* total_ms_
     if (rc) return rc;
     MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.gctl, 0, sizeof(GlobalCtl), h->stream));
     if ((rc = magi_launch_prepare(h, n_chains, h->stream))) return rc;
+    if ((rc = magi_launch_plan_eval(h, n_chains, h->stream))) return rc;
+    h->sampler_ready = false;          // the chain state is clobbered by the timing launches
     float ms = 0.f;
     // warm
     for (int i = 0; i < 3; ++i) {
@@ -587,8 +595,8 @@ int magi_time_gradient(magi_handle* h, int n_chains, int reps, double* total_ms_
             for (int i = 0; i < reps; ++i) {
                 if (ph <= 3) rc = magi_launch_phase(h, ph, n_chains, h->stream);
                 else if (ph == 4) rc = magi_launch_finalize(h, n_chains, h->d_fin, h->stream);
-                else if (ph == 5) rc = magi_launch_fused(h, n_chains, h->stream);
-                else rc = magi_launch_finalize_fused(h, n_chains, h->d_fin, h->stream);
+                else if (ph == 5) rc = magi_launch_leap(h, n_chains, h->stream);
+                else rc = magi_launch_leap_finalize(h, n_chains, h->d_fin, h->stream);
                 if (rc) return rc;
             }
             MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t1, h->stream));

@@ -14,7 +14,6 @@
 // as the reference's pinv outputs are) matrices.  Mt = m^T is stored separately so the transposed
 // product also reads rows.
 #include "magi_internal.h"
-#include "fused_pass.h"
 
 namespace {
 
@@ -216,217 +215,6 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_finalize(DevProblem pb, D
     }
 }
 
-// =============================================================================================
-// Single-phase mat-vecs of the sampler: for row (d, i) and every chain
-//     V_CX = FH xc,  V_R = FE xc,  V_ETF = FEt f,  V_KR = FK f        (f = drift(X, theta))
-// All four depend only on the state, so a gradient is ONE streaming kernel + the tail instead of
-// three dependent phases: two grid-wide dependencies and two kernel boundaries fewer per leapfrog.
-// One wave per row, the first batch of matrix loads is issued BEFORE the LDS staging of the
-// source vectors so the staging latency hides under the stream.
-// =============================================================================================
-template <int NC, int DRIFT>
-__device__ inline void stage_sources(const DevProblem& pb, const DevChains& ch, int d, int c0, int j0, int count, int joff,
-                                     double* xs, double* fs, int pitch) {
-    using DR = DriftT<DRIFT>;
-    // elements [j0 + joff + 0 .. count) of xc_d and f_d for NC chains; zero outside [0, N)
-    for (int idx = threadIdx.x; idx < NC * count; idx += 256) {
-        const int c = idx / count, w = idx - c * count;
-        const int jg = j0 + joff + w, cc = c0 + c;
-        double xv = 0.0, fv = 0.0;
-        if (cc < ch.n_chains && jg >= 0 && jg < pb.N) {
-            const double* q = ch.vec + vec_off(pb, cc, V_Q);
-            const double* par = ch.par + (size_t)cc * PAR_COUNT;
-            double xg[DR::D], th[DR::P], fo[DR::D];
-#pragma unroll
-            for (int dd = 0; dd < DR::D; ++dd) xg[dd] = q[dd * pb.N + jg];
-#pragma unroll
-            for (int k = 0; k < DR::P; ++k) th[k] = par[PAR_TH + k];
-            DR::f(xg, th, fo);
-            double xd = xg[0];
-            fv = fo[0];
-#pragma unroll
-            for (int dd = 1; dd < DR::D; ++dd) if (d == dd) { xd = xg[dd]; fv = fo[dd]; }
-            xv = xd - pb.mu[d];
-        }
-        xs[c * pitch + w] = xv;
-        fs[c * pitch + w] = fv;
-    }
-}
-
-template <int NC, int DRIFT>
-__global__ __launch_bounds__(256) void k_fused_dense(DevProblem pb, DevChains ch, int TJ) {
-    if (ch.gctl->all_done) return;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int U = 4;
-    const int N = pb.N, ld = pb.ldf, d = blockIdx.y;
-    const int c0 = blockIdx.z * NC;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
-    const int rr = min(row, N - 1);
-    const size_t ro = ((size_t)d * N + rr) * ld;
-    const double2* ph = reinterpret_cast<const double2*>(pb.FH + ro);
-    const double2* pe = reinterpret_cast<const double2*>(pb.FE + ro);
-    const double2* pt = reinterpret_cast<const double2*>(pb.FEt + ro);
-    const double2* pk = reinterpret_cast<const double2*>(pb.FK + ro);
-    double* xs = lds;
-    double* fs = lds + NC * TJ;
-    const double2 z2 = make_double2(0.0, 0.0);
-
-    double ah[NC], ae[NC], at[NC], ak[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) { ah[c] = 0.0; ae[c] = 0.0; at[c] = 0.0; ak[c] = 0.0; }
-
-    for (int j0 = 0; j0 < ld; j0 += TJ) {
-        const int tjl = min(TJ, ld - j0);
-        const int n2 = tjl >> 1, jb = j0 >> 1;
-        double2 h[U], e[U], t[U], k[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int jj = lane + 64 * u;
-            const bool ok = jj < n2;
-            h[u] = ok ? ph[jb + jj] : z2; e[u] = ok ? pe[jb + jj] : z2;
-            t[u] = ok ? pt[jb + jj] : z2; k[u] = ok ? pk[jb + jj] : z2;
-        }
-        stage_sources<NC, DRIFT>(pb, ch, d, c0, j0, tjl, 0, xs, fs, TJ);
-        __syncthreads();
-        for (int base = 0; base < n2; base += 64 * U) {
-            double2 hn[U], en[U], tn[U], kn[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int jj = base + 64 * U + lane + 64 * u;
-                const bool ok = jj < n2;
-                hn[u] = ok ? ph[jb + jj] : z2; en[u] = ok ? pe[jb + jj] : z2;
-                tn[u] = ok ? pt[jb + jj] : z2; kn[u] = ok ? pk[jb + jj] : z2;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int jj = base + lane + 64 * u;
-                if (jj < n2) {
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        const double2 xv = reinterpret_cast<const double2*>(xs + c * TJ)[jj];
-                        const double2 fv = reinterpret_cast<const double2*>(fs + c * TJ)[jj];
-                        ah[c] = fma(h[u].x, xv.x, ah[c]); ah[c] = fma(h[u].y, xv.y, ah[c]);
-                        ae[c] = fma(e[u].x, xv.x, ae[c]); ae[c] = fma(e[u].y, xv.y, ae[c]);
-                        at[c] = fma(t[u].x, fv.x, at[c]); at[c] = fma(t[u].y, fv.y, at[c]);
-                        ak[c] = fma(k[u].x, fv.x, ak[c]); ak[c] = fma(k[u].y, fv.y, ak[c]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) { h[u] = hn[u]; e[u] = en[u]; t[u] = tn[u]; k[u] = kn[u]; }
-        }
-        __syncthreads();
-    }
-    double vh = 0.0, ve = 0.0, vt = 0.0, vk = 0.0;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const double s0 = wave_sum(ah[c]), s1 = wave_sum(ae[c]), s2 = wave_sum(at[c]), s3 = wave_sum(ak[c]);
-        if (lane == c) { vh = s0; ve = s1; vt = s2; vk = s3; }
-    }
-    if (lane < NC && row < N && c0 + lane < ch.n_chains) {
-        double* vb = ch.vec + vec_off(pb, c0 + lane, 0);
-        const size_t o = (size_t)d * N + row;
-        vb[(size_t)V_CX * pb.dimp + o] = vh;
-        vb[(size_t)V_R * pb.dimp + o] = ve;
-        vb[(size_t)V_ETF * pb.dimp + o] = vt;
-        vb[(size_t)V_KR * pb.dimp + o] = vk;
-    }
-}
-
-// banded fused stacks: rows hold columns [i - bf, i + bf]; 4 rows per workgroup
-template <int NC, int DRIFT>
-__global__ __launch_bounds__(256) void k_fused_band(DevProblem pb, DevChains ch) {
-    if (ch.gctl->all_done) return;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int RB = 4;
-    const int N = pb.N, ld = pb.ldf, b = pb.bandf, W = 2 * b + 1, d = blockIdx.y;
-    const int c0 = blockIdx.z * NC;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rb = blockIdx.x * RB;
-    const int WL = RB + 2 * b;
-    double* xs = lds;
-    double* fs = lds + NC * WL;
-    stage_sources<NC, DRIFT>(pb, ch, d, c0, rb - b, WL, 0, xs, fs, WL);
-    __syncthreads();
-    const int row = rb + wave, rr = min(row, N - 1);
-    const size_t ro = ((size_t)d * N + rr) * ld;
-    const double *ph = pb.FH + ro, *pe = pb.FE + ro, *pt = pb.FEt + ro, *pk = pb.FK + ro;
-    double ah[NC], ae[NC], at[NC], ak[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) { ah[c] = 0.0; ae[c] = 0.0; at[c] = 0.0; ak[c] = 0.0; }
-    const int xoff = rr - rb;
-#pragma unroll 4
-    for (int kk = lane; kk < W; kk += 64) {
-        const double h = ph[kk], e = pe[kk], t = pt[kk], k = pk[kk];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const double xv = xs[c * WL + xoff + kk], fv = fs[c * WL + xoff + kk];
-            ah[c] = fma(h, xv, ah[c]); ae[c] = fma(e, xv, ae[c]);
-            at[c] = fma(t, fv, at[c]); ak[c] = fma(k, fv, ak[c]);
-        }
-    }
-    double vh = 0.0, ve = 0.0, vt = 0.0, vk = 0.0;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const double s0 = wave_sum(ah[c]), s1 = wave_sum(ae[c]), s2 = wave_sum(at[c]), s3 = wave_sum(ak[c]);
-        if (lane == c) { vh = s0; ve = s1; vt = s2; vk = s3; }
-    }
-    if (lane < NC && row < N && c0 + lane < ch.n_chains) {
-        double* vb = ch.vec + vec_off(pb, c0 + lane, 0);
-        const size_t o = (size_t)d * N + row;
-        vb[(size_t)V_CX * pb.dimp + o] = vh;
-        vb[(size_t)V_R * pb.dimp + o] = ve;
-        vb[(size_t)V_ETF * pb.dimp + o] = vt;
-        vb[(size_t)V_KR * pb.dimp + o] = vk;
-    }
-}
-
-template <int DRIFT>
-__global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_finalize_fused(DevProblem pb, DevChains ch, double* out) {
-    __shared__ double sh[(FP_KMAX + 1) * 16];
-    __shared__ double shs[8];
-    const int c = blockIdx.x;
-    double* vb = ch.vec + vec_off(pb, c, 0);
-    LeafArgs la;
-    const PassOut po = fused_pass<DRIFT>(pb, vb, ch.par + (size_t)c * PAR_COUNT, sh, shs, la);
-    if (threadIdx.x == 0 && out) {
-        out[c * 8 + 0] = po.L;
-        out[c * 8 + 1] = po.t12;
-        out[c * 8 + 2] = 0.0;
-        out[c * 8 + 3] = po.t3;
-        out[c * 8 + 4] = po.t4;
-    }
-}
-
-template <int NC, int DRIFT>
-int launch_fused_nd(magi_handle* h, int n_chains, hipStream_t s) {
-    const DevProblem& pb = h->pb;
-    const int groups = (n_chains + NC - 1) / NC;
-    if (pb.bandf < 0) {
-        int TJ = pb.ldf;
-        const int cap = (64 * 1024) / (16 * NC);
-        if (TJ > cap) TJ = cap & ~127;
-        dim3 grid((pb.N + 3) / 4, pb.D, groups);
-        hipLaunchKernelGGL((k_fused_dense<NC, DRIFT>), grid, dim3(256), (size_t)2 * NC * TJ * sizeof(double), s, pb, h->ch, TJ);
-    } else {
-        dim3 grid((pb.N + 3) / 4, pb.D, groups);
-        hipLaunchKernelGGL((k_fused_band<NC, DRIFT>), grid, dim3(256), (size_t)2 * NC * (4 + 2 * pb.bandf) * sizeof(double), s, pb, h->ch);
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("fused launch: ") + hipGetErrorString(e));
-    return MAGI_OK;
-}
-
-template <int NC>
-int launch_fused_nc(magi_handle* h, int n_chains, hipStream_t s) {
-    switch (h->pb.drift) {
-    case MAGI_DRIFT_SEIR3: return launch_fused_nd<NC, MAGI_DRIFT_SEIR3>(h, n_chains, s);
-    case MAGI_DRIFT_SEIR4: return launch_fused_nd<NC, MAGI_DRIFT_SEIR4>(h, n_chains, s);
-    default: return launch_fused_nd<NC, MAGI_DRIFT_SIRW>(h, n_chains, s);
-    }
-}
-
 // transformed parameters of the states in V_Q (API path; the sampler's tail does this itself)
 __global__ void k_prepare(DevProblem pb, DevChains ch) {
     const int c = blockIdx.x, j = threadIdx.x;
@@ -477,25 +265,6 @@ int magi_launch_gradient(magi_handle* h, int n_chains, hipStream_t s) {
     if ((rc = launch_phase<1>(h, n_chains, s))) return rc;
     if ((rc = launch_phase<2>(h, n_chains, s))) return rc;
     return launch_phase<3>(h, n_chains, s);
-}
-
-int magi_launch_fused(magi_handle* h, int n_chains, hipStream_t s) {
-    if (n_chains >= 8) return launch_fused_nc<8>(h, n_chains, s);
-    if (n_chains >= 3) return launch_fused_nc<4>(h, n_chains, s);
-    if (n_chains == 2) return launch_fused_nc<2>(h, n_chains, s);
-    return launch_fused_nc<1>(h, n_chains, s);
-}
-
-int magi_launch_finalize_fused(magi_handle* h, int n_chains, double* d_out, hipStream_t s) {
-    const dim3 g(n_chains), b(MAGI_TAIL_THREADS);
-    switch (h->pb.drift) {
-    case MAGI_DRIFT_SEIR3: hipLaunchKernelGGL(k_finalize_fused<MAGI_DRIFT_SEIR3>, g, b, 0, s, h->pb, h->ch, d_out); break;
-    case MAGI_DRIFT_SEIR4: hipLaunchKernelGGL(k_finalize_fused<MAGI_DRIFT_SEIR4>, g, b, 0, s, h->pb, h->ch, d_out); break;
-    default: hipLaunchKernelGGL(k_finalize_fused<MAGI_DRIFT_SIRW>, g, b, 0, s, h->pb, h->ch, d_out); break;
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("finalize_fused launch: ") + hipGetErrorString(e));
-    return MAGI_OK;
 }
 
 int magi_launch_prepare(magi_handle* h, int n_chains, hipStream_t s) {

@@ -46,9 +46,12 @@ struct DevProblem {
 
 // Per-chain vector slots (each dimp doubles) -------------------------------------------------
 enum VecSlot {
-    V_Q = 0,     // current leaf position: X comp-major [D][N], sigma_pre[D], theta_pre[P]
-    V_P,         // momentum (holds the half-step momentum while a gradient is in flight)
-    V_G,         // UNtempered gradient of L at V_Q
+    V_Q = 0,     // position buffer 0: X comp-major [D][N], sigma_pre[D], theta_pre[P]
+    V_Q1,        // position buffer 1 (the sampler ping-pongs: plan.cur selects the one being evaluated)
+    V_P,         // half-step momentum buffer 0
+    V_P1,        // half-step momentum buffer 1
+    V_PLEAF,     // momentum at the leaf (after the full step)
+    V_G,         // UNtempered gradient of L at the evaluated position
     V_CX,        // Csym * xc           [D][N]
     V_R,         // f - m xc            [D][N]
     V_KR,        // Ksym * r            [D][N]   (fused path: Ksym * f)
@@ -82,7 +85,7 @@ struct ChainCtl {
     int sub_lf;
     int da_step;
     int done_epoch;   // last run epoch in which this chain reported itself idle
-    int pad0;
+    int cur;          // position buffer holding the state being evaluated
     long long chain_id;
     long long total_leapfrogs;
     double eps;         // step size of this transition (> 0)
@@ -113,9 +116,33 @@ struct GlobalCtl {
     int pad[3];
 };
 
+// What the streaming kernel's epilogue must do for a chain in the next leapfrog slot; written by the
+// tail (or the host for API calls), read by every workgroup of k_leap_*.
+struct LeafPlan {
+    int active;        // 0: leave the chain's state alone (idle chain)
+    int leaf;          // 1: complete the leapfrog (momentum, sums, checkpoint, speculative next state)
+    int cur;           // position / half-momentum buffer being evaluated (0/1)
+    int even;          // write the U-turn checkpoint of this leaf
+    int ck_slot;       // checkpoint slot to write (popcount of the leaf index)
+    int nchk;          // U-turn checks folded into the epilogue (0..4)
+    int chk_slot[4];   // their checkpoint slots
+    unsigned leaf_ctr; // Philox counters of the two uniforms this leaf may need (STREAM_LEAF / STREAM_MERGE)
+    unsigned depth;
+    unsigned step_k;
+    unsigned chain_id;
+    double hs;         // 0.5 * eps * beta_k (signed)
+    double eps;        // signed step
+    unsigned long long seed;
+};
+
+constexpr int PART_K = 24;   // partial sums per workgroup and chain: t12, ss[D], tp[P], pp, 4 x (dA, dB)
+
 struct DevChains {
     double* vec;          // [n_chains][V_COUNT][dimp]
     ChainCtl* ctl;        // [n_chains]
+    LeafPlan* plan;       // [n_chains]
+    double* part;         // [n_chains][PART_K][n_wg] partial sums of the streaming kernel
+    int n_wg;             // workgroups along the grid axis of k_leap_*
     double* par;          // [n_chains][PAR_COUNT] transformed parameters of the state in V_Q
     GlobalCtl* gctl;
     int n_chains;
@@ -207,12 +234,15 @@ __device__ inline double rng_normal_elem(unsigned int e, unsigned int step, unsi
 // writes V_Q (fp64 exp/log are ~100-instruction sequences: keeping them out of the per-row
 // epilogues and out of the 1024-thread reduce is worth tens of microseconds per gradient).
 // ------------------------------------------------------------------------------------------
-enum ParOff { PAR_TH = 0, PAR_SGT = 8, PAR_LJT = 16, PAR_SIG2 = 24, PAR_SGS = 28, PAR_LJS = 32, PAR_LOG2PIS = 36, PAR_COUNT = 64 };
+enum ParOff { PAR_TH = 0, PAR_SGT = 8, PAR_LJT = 16, PAR_SIG2 = 24, PAR_SGS = 28, PAR_LJS = 32, PAR_LOG2PIS = 36,
+              PAR_ULEAF = 56, PAR_UMERGE = 57 /* log1p(-U) draws of the leaf in flight, made by k_leap_*'s service block */,
+              PAR_COUNT = 64 };
 
 // entry j of the parameter block: j < D -> sigma_pre[j], else theta_pre[j - D]
 __device__ inline void compute_par_entry(const DevProblem& pb, int j, double pre, double* par) {
-    const double sp = softplus_ref(pre);
-    const double sg = sigmoid(pre);
+    const double e = m_exp(pre);
+    const double sp = m_log(1.0 + e);          // magi_v2.py:318-319
+    const double sg = e / (1.0 + e);           // d softplus / d pre (= 1/(1+exp(-pre)) up to rounding)
     if (j < pb.D) {
         const double lb = (j == 0) ? pb.LB[0] : (j == 1) ? pb.LB[1] : (j == 2) ? pb.LB[2] : pb.LB[3];
         const double s2 = sp + lb;
@@ -331,6 +361,12 @@ template <> struct DriftT<MAGI_DRIFT_SEIR3> {
         o[1] = (th[2] * E) - (th[1] * I);
         o[2] = th[1] * I;
     }
+    static __device__ __forceinline__ double f1(int d, const double (&x)[3], const double (&th)[3]) {
+        const double E = x[0], I = x[1], R = x[2], S = 1.0 - ((E + I) + R);
+        if (d == 0) return (th[0] * S * I) - (th[2] * E);
+        if (d == 1) return (th[2] * E) - (th[1] * I);
+        return th[1] * I;
+    }
     // c[d] = sum_d' g[d'] df_d'/dx_d ; t[p] += sum_d g[d] df_d/dtheta_p
     static __device__ __forceinline__ void jt(const double (&x)[3], const double (&th)[3], const double (&g)[3], double (&c)[3], double (&t)[3]) {
         const double E = x[0], I = x[1], R = x[2], S = 1.0 - ((E + I) + R);
@@ -353,6 +389,13 @@ template <> struct DriftT<MAGI_DRIFT_SEIR4> {
         o[2] = th[2] * E - th[1] * I;
         o[3] = th[1] * I;
     }
+    static __device__ __forceinline__ double f1(int d, const double (&x)[4], const double (&th)[3]) {
+        const double S = x[0], E = x[1], I = x[2];
+        if (d == 0) return -th[0] * S * I;
+        if (d == 1) return th[0] * S * I - th[2] * E;
+        if (d == 2) return th[2] * E - th[1] * I;
+        return th[1] * I;
+    }
     static __device__ __forceinline__ void jt(const double (&x)[4], const double (&th)[3], const double (&g)[4], double (&c)[4], double (&t)[3]) {
         const double S = x[0], E = x[1], I = x[2];
         const double b = th[0], gm = th[1], s = th[2];
@@ -374,6 +417,13 @@ template <> struct DriftT<MAGI_DRIFT_SIRW> {
         o[1] = th[0] * S * I - th[1] * I;
         o[2] = th[1] * I - th[2] * R + th[3] * I * W;
         o[3] = th[2] * R - th[3] * I * W - th[4] * W;
+    }
+    static __device__ __forceinline__ double f1(int d, const double (&x)[4], const double (&th)[5]) {
+        const double S = x[0], I = x[1], R = x[2], W = x[3];
+        if (d == 0) return -th[0] * S * I + th[4] * W;
+        if (d == 1) return th[0] * S * I - th[1] * I;
+        if (d == 2) return th[1] * I - th[2] * R + th[3] * I * W;
+        return th[2] * R - th[3] * I * W - th[4] * W;
     }
     static __device__ __forceinline__ void jt(const double (&x)[4], const double (&th)[5], const double (&g)[4], double (&c)[4], double (&t)[5]) {
         const double S = x[0], I = x[1], R = x[2], W = x[3];
@@ -614,8 +664,10 @@ int magi_fail(magi_handle* h, int code, const std::string& msg);
 int magi_launch_gradient(magi_handle* h, int n_chains, hipStream_t s);        // phases 1-3
 int magi_launch_phase(magi_handle* h, int phase, int n_chains, hipStream_t s);
 int magi_launch_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s);
-int magi_launch_fused(magi_handle* h, int n_chains, hipStream_t s);            // single-phase mat-vecs
-int magi_launch_finalize_fused(magi_handle* h, int n_chains, double* d_out, hipStream_t s);
+int magi_launch_leap(magi_handle* h, int n_chains, hipStream_t s);             // single-phase mat-vecs + leapfrog epilogue
+int magi_launch_leap_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s);
+int magi_leap_wgs(const DevProblem& pb);
+int magi_launch_plan_eval(magi_handle* h, int n_chains, hipStream_t s);        // plan: evaluate buffer 0, no leapfrog                                       // workgroups along the grid axis
 // build.hip: E = Ks M, H = Cs + M^T E for D dense [N][N] components (H overwrites Cs)
 int magi_fused_operators(magi_handle* h, int N, int D, double* dCs_inout_H, const double* dM, const double* dKs, double* dE);
 int magi_launch_prepare(magi_handle* h, int n_chains, hipStream_t s);   // fills par from V_Q

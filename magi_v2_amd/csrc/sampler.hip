@@ -20,7 +20,7 @@
 // every big helper has a single call site, fp64 transcendentals are noinline, and the rare
 // transition-end work sits behind one branch at the bottom.
 #include "magi_internal.h"
-#include "fused_pass.h"
+#include "leap_reduce.h"
 
 namespace {
 
@@ -66,10 +66,35 @@ __device__ __noinline__ void dual_averaging_eval(double target_accept, int n_ada
     out[3] = new_log_avg;
 }
 
+// plan of the leaf with index c.it of the current subtree (evaluated from buffer c.cur)
+__device__ __forceinline__ LeafPlan make_leaf_plan(const ChainCtl& c, unsigned long long seed) {
+    LeafPlan p{};
+    p.active = 1;
+    p.leaf = 1;
+    p.cur = c.cur;
+    const int it = c.it;
+    p.even = ((it & 1) == 0) ? 1 : 0;
+    p.ck_slot = __popc((unsigned)it);
+    int nk = 0;
+    if (!p.even)
+        for (int kk = 1; ((it + 1) & ((1 << kk) - 1)) == 0 && (1 << kk) <= c.nsteps; ++kk) nk = kk;
+    p.nchk = min(nk, 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p.chk_slot[k] = (k < p.nchk) ? __popc((unsigned)(it + 1 - (2 << k))) : 0;
+    p.eps = c.dir * c.eps;
+    p.hs = 0.5 * p.eps * c.beta_k;
+    p.leaf_ctr = (unsigned)c.leaf_ctr;
+    p.depth = (unsigned)c.depth;
+    p.step_k = (unsigned)c.k;
+    p.chain_id = (unsigned)c.chain_id;
+    p.seed = seed;
+    return p;
+}
+
 template <int DRIFT>
 __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevChains ch, SamplerCfgDev cfg) {
-    __shared__ double sh[(FP_KMAX + 1) * 16];
-    __shared__ double shs[16];
+    __shared__ double sh[25 * 16];
+    __shared__ double shs[24];
     if (ch.gctl->all_done) return;
     const int chain = blockIdx.x;
     const int tid = threadIdx.x;
@@ -81,6 +106,7 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
     double* vb = ch.vec + vec_off(pb, chain, 0);
     double* par = ch.par + (size_t)chain * PAR_COUNT;
     const TailVecs v = tail_vecs(pb, vb);
+    const size_t sv = pb.dimp;
 
     bool do_sample = false, do_doubling = false;     // what to set up before returning
 
@@ -99,126 +125,110 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
             return;
         }
     } else {
-        // ---- gradient at V_Q (+ for a leaf: momentum half step, sums, checkpoint, two U-turn tests) -----
-        const bool leaf = (c.phase == PH_LEAF);
+        const LeafPlan lp = ch.plan[chain];          // what k_leap_* just executed for this chain
+        const bool leaf = lp.leaf != 0;
         MAGI_STAMP(par, 1);
-        if (leaf) {
-            // data-independent uniforms of this leaf / a possible merge: drawn by two otherwise idle waves
-            if (tid == 64) shs[8] = m_log1p(-rng_uniform((unsigned)c.leaf_ctr, (unsigned)c.k, (unsigned)c.chain_id, STREAM_LEAF, cfg.seed));
-            if (tid == 128) shs[9] = m_log1p(-rng_uniform((unsigned)c.depth, (unsigned)c.k, (unsigned)c.chain_id, STREAM_MERGE, cfg.seed));
-        } else if (tid == 64) {
-            shs[8] = cfg.anneal ? temperature(0, cfg.min_temp) : 1.0;
-        }
-        const double eps = c.dir * c.eps;
-        const double hs = 0.5 * eps * c.beta_k;
-        const int it = c.it;
-        const bool even = (it & 1) == 0;
-        int nk = 0;                              // U-turn checks due at this leaf (balanced sub-subtrees closing here)
-        if (leaf && !even)
-            for (int kk = 1; ((it + 1) & ((1 << kk) - 1)) == 0 && (1 << kk) <= c.nsteps; ++kk) nk = kk;
-        LeafArgs la;
-        la.leaf = leaf;
-        la.hs = hs;
-        la.even = even;
-        la.ckp_w = v.ckp + (size_t)__popc((unsigned)it) * pb.dimp;
-        la.ckr_w = v.ckrho + (size_t)__popc((unsigned)it) * pb.dimp;
-        la.nchk = min(nk, 2);
-        if (nk >= 1) { const int s1 = __popc((unsigned)(it + 1 - 2)); la.cp1 = v.ckp + (size_t)s1 * pb.dimp; la.cr1 = v.ckrho + (size_t)s1 * pb.dimp; }
-        if (nk >= 2) { const int s2 = __popc((unsigned)(it + 1 - 4)); la.cp2 = v.ckp + (size_t)s2 * pb.dimp; la.cr2 = v.ckrho + (size_t)s2 * pb.dimp; }
-
-        const PassOut po = fused_pass<DRIFT>(pb, vb, par, sh, shs, la);
+        // (the leaf's two uniform draws were made by k_leap_*'s service block: par[PAR_ULEAF / PAR_UMERGE])
+        const double u_leaf = par[PAR_ULEAF], u_merge = par[PAR_UMERGE];
+        if (!leaf && tid == 64) shs[16] = cfg.anneal ? temperature(0, cfg.min_temp) : 1.0;
+        // ---- add the streaming kernel's partial sums, finish the parameter entries -----------------------
+        const ReduceOut ro = leap_reduce<DRIFT>(pb, ch, chain, vb, par, lp, sh, shs);
         MAGI_STAMP(par, 4);
-        const double L = po.L;
+        const double L = ro.L;
+        double* qcur = vb + (size_t)(V_Q + lp.cur) * sv;      // the state that was evaluated
+        double* pleaf = vb + (size_t)V_PLEAF * sv;
 
         if (!leaf) {
             // bootstrap_results: target / gradient at the initial state, cached at beta_temp(0)
-            for (int e = tid; e < dim; e += blockDim.x) { v.candq[e] = v.q[e]; v.candg[e] = v.g[e]; }
+            for (int e = tid; e < dim; e += blockDim.x) { v.candq[e] = qcur[e]; v.candg[e] = v.g[e]; }
             c.cand_L = L;
-            c.beta_cache = shs[8];
+            c.beta_cache = shs[16];
             if (c.k < stop_k) do_sample = true;
             else c.phase = PH_IDLE;
         } else {
             c.L_cur = L;
             c.total_leapfrogs += 1;
+            const int it = c.it;
+            int nk = 0;
+            if (!lp.even)
+                for (int kk = 1; ((it + 1) & ((1 << kk) - 1)) == 0 && (1 << kk) <= c.nsteps; ++kk) nk = kk;
             bool no_u = true;
-            if (nk >= 1) no_u = no_u && (po.dA1 > 0.0) && (po.dB1 > 0.0);
-            if (nk >= 2) no_u = no_u && (po.dA2 > 0.0) && (po.dB2 > 0.0);
-            for (int kk = 3; kk <= nk; ++kk) {       // one leaf in eight gets here
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nk) no_u = no_u && (ro.dA[k] > 0.0) && (ro.dB[k] > 0.0);
+            for (int kk = 5; kk <= nk; ++kk) {       // one leaf in 32 gets here
                 const int left = it + 1 - (1 << kk);
-                const double* cp = v.ckp + (size_t)__popc((unsigned)left) * pb.dimp;
-                const double* cr = v.ckrho + (size_t)__popc((unsigned)left) * pb.dimp;
+                const double* cp = v.ckp + (size_t)__popc((unsigned)left) * sv;
+                const double* cr = v.ckrho + (size_t)__popc((unsigned)left) * sv;
                 double dots[2] = {0.0, 0.0};
                 for (int e = tid; e < dim; e += blockDim.x) {
                     const double df = v.rhosub[e] - cr[e];
                     dots[0] = fma(df, cp[e], dots[0]);
-                    dots[1] = fma(df, v.p[e], dots[1]);
+                    dots[1] = fma(df, pleaf[e], dots[1]);
                 }
                 block_sum<2>(dots, sh);
                 no_u = no_u && (dots[0] > 0.0) && (dots[1] > 0.0);
             }
 
             // ---- energy, multinomial proposal inside the subtree --------------------------------------
-            double energy = c.beta_k * L - 0.5 * po.pp;
+            double energy = c.beta_k * L - 0.5 * ro.pp;
             if (isnan(energy)) energy = -INFINITY;
             const double ediff = energy - c.init_energy;
             const bool not_divergent = (-ediff < cfg.max_energy_diff);
-            if (tid == 0) shs[10] = logaddexp(c.sub_weight, ediff);
-            if (tid == 192) shs[11] = m_exp(fmin(ediff, 0.0));
+            if (tid == 0) shs[18] = logaddexp(c.sub_weight, ediff);
+            if (tid == 192) shs[19] = m_exp(fmin(ediff, 0.0));
             __syncthreads();
             MAGI_STAMP(par, 5);
-            const double wsum_leaf = shs[10];
-            const bool accept_leaf = (shs[8] <= ediff - wsum_leaf);
+            const double wsum_leaf = shs[18];
+            const bool accept_leaf = (u_leaf <= ediff - wsum_leaf);
             c.leaf_ctr += 1;
             if (accept_leaf) { c.sub_L = L; c.sub_energy = energy; }
             c.sub_weight = wsum_leaf;
             const bool cont_tree = not_divergent && (c.cont != 0);
             c.cont = (no_u && cont_tree) ? 1 : 0;
             c.nd = (c.nd && not_divergent) ? 1 : 0;
-            if (cont_tree) c.e_sum_sub += shs[11];
+            if (cont_tree) c.e_sum_sub += shs[19];
             c.sub_lf += 1;
             c.it = it + 1;
 
             if (c.it < c.nsteps && c.cont) {
-                // ---- proposal copy + next leaf of the same subtree (half step + position): one sweep -----
-                for (int e = tid; e < dim; e += blockDim.x) {
-                    const double qv = v.q[e], gv = v.g[e];
-                    if (accept_leaf) { v.subq[e] = qv; v.subg[e] = gv; }
-                    const double ph = v.p[e] + hs * gv;
-                    v.p[e] = ph;
-                    const double qn = qv + eps * ph;
-                    v.q[e] = qn;
-                    if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par);
+                // ---- the speculative next leaf stands: flip buffers, publish its plan -------------------------
+                if (accept_leaf)                     // proposal copy (expected O(log n) times per subtree)
+                    for (int e = tid; e < dim; e += blockDim.x) { v.subq[e] = qcur[e]; v.subg[e] = v.g[e]; }
+                c.cur = lp.cur ^ 1;
+                if (tid == 0) {
+                    ch.plan[chain] = make_leaf_plan(c, cfg.seed);
+                    ch.ctl[chain] = c;
                 }
                 MAGI_STAMP(par, 6);
-                if (tid == 0) ch.ctl[chain] = c;
                 return;
             }
 
             // ---- subtree finished: merge into the trajectory (biased progressive sampling) ---------------
             const double tree_weight = c.cont ? c.sub_weight : -INFINITY;
-            if (tid == 0) shs[12] = logaddexp(tree_weight, c.cand_weight);
+            if (tid == 0) shs[20] = logaddexp(tree_weight, c.cand_weight);
             const double thresh = tree_weight - c.cand_weight;
-            const bool choose = (shs[9] <= thresh) && (c.cont != 0);
+            const bool choose = (u_merge <= thresh) && (c.cont != 0);
             double* pe = (c.dir > 0) ? v.pR : v.pL;
             double* qe = (c.dir > 0) ? v.qR : v.qL;
             double* ge = (c.dir > 0) ? v.gR : v.gL;
             const double* po_ = (c.dir > 0) ? v.pL : v.pR;    // the other end
             double dots[2] = {0.0, 0.0};
             for (int e = tid; e < dim; e += blockDim.x) {
-                const double qv = v.q[e], gv = v.g[e];
+                const double qv = qcur[e], gv = v.g[e];
                 // the subtree proposal is this leaf if it was just accepted, else what V_SUB holds
                 const double sq = accept_leaf ? qv : v.subq[e], sg = accept_leaf ? gv : v.subg[e];
                 if (choose) { v.candq[e] = sq; v.candg[e] = sg; }
-                const double pn = v.p[e];
+                const double pn = pleaf[e];
                 pe[e] = pn; qe[e] = qv; ge[e] = gv;
                 const double rr = v.rho[e] + v.rhosub[e];
                 v.rho[e] = rr;
                 dots[0] = fma(rr, po_[e], dots[0]);
                 dots[1] = fma(rr, pn, dots[1]);
             }
-            block_sum<2>(dots, sh);        // (its barriers publish shs[12])
+            block_sum<2>(dots, sh);        // (its barriers publish shs[20])
             if (choose) { c.cand_L = c.sub_L; c.cand_energy = c.sub_energy; c.cand_bfac = c.beta_k; c.is_accepted = 1; }
-            c.cand_weight = shs[12];
+            c.cand_weight = shs[20];
             if (c.dir > 0) { c.LR = c.L_cur; c.bfacR = c.beta_k; } else { c.LL = c.L_cur; c.bfacL = c.beta_k; }
             const bool no_u_traj = (dots[0] > 0.0) && (dots[1] > 0.0);
             c.e_sum += c.e_sum_sub;
@@ -260,6 +270,8 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
                     c.phase = PH_IDLE;
                     c.done_epoch = epoch;
                     if (tid == 0) {
+                        LeafPlan off{};
+                        ch.plan[chain] = off;
                         ch.ctl[chain] = c;
                         const int done = atomicAdd(&ch.gctl->done_chains, 1) + 1;
                         if (done >= ch.gctl->n_chains) ch.gctl->all_done = 1;
@@ -315,11 +327,14 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
         const double bf = fwd ? c.bfacR : c.bfacL;
         const double eps = c.dir * c.eps;
         const double hs = 0.5 * eps * bf;
+        c.cur ^= 1;
+        double* qw = vb + (size_t)(V_Q + c.cur) * sv;
+        double* pw = vb + (size_t)(V_P + c.cur) * sv;
         for (int e = tid; e < dim; e += blockDim.x) {
             const double ph = pe[e] + hs * ge[e];
-            v.p[e] = ph;
+            pw[e] = ph;
             const double qn = qe[e] + eps * ph;
-            v.q[e] = qn;
+            qw[e] = qn;
             v.rhosub[e] = 0.0;
             if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par);
         }
@@ -331,6 +346,10 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
         c.cont = 1;
         c.nd = c.not_div;
         c.phase = PH_LEAF;
+        if (tid == 0) ch.plan[chain] = make_leaf_plan(c, cfg.seed);
+    } else if (tid == 0) {
+        LeafPlan off{};                  // idle after the bootstrap gradient
+        ch.plan[chain] = off;
     }
     if (tid == 0) ch.ctl[chain] = c;
 }
@@ -347,6 +366,10 @@ __global__ void k_init_chains(DevChains ch, SamplerCfgDev cfg, const long long* 
     if (i >= ch.n_chains) return;
     ChainCtl c{};
     c.phase = PH_INIT;
+    c.cur = 0;
+    LeafPlan p{};
+    p.active = 1;                      // bootstrap gradient at buffer 0, no leapfrog
+    ch.plan[i] = p;
     c.chain_id = chain_ids ? chain_ids[i] : (long long)i;
     c.da_step_size = cfg.step_size;
     c.da_log_shrink = log(10.0 * cfg.step_size);

@@ -16,16 +16,12 @@ eng.set_problem(Xi.mean(axis=0), N_ds.astype(float), idx, y, beta, LB, "seir4")
 cfg = eng.default_cfg(num_results=30, num_burnin_steps=30, stale_cache=0)
 eng.sampler_init(cfg, Xhat, sp, tp, seed=1)
 eng.sampler_run(30)
-acc = []
-for rep in range(40):
-    eng.sampler_run(1) if False else None
-import time
-# sample stamps repeatedly while the chain runs one step at a time
 rows = []
 for rep in range(25):
     eng.sampler_run(1)
     p = eng.debug_par(0)[40:48]
-    rows.append(np.diff(p) * 10.0)          # 100 MHz ticks -> ns
+    rows.append(p)
 rows = np.array(rows)
-print("ns per stage [ctl, uniforms+setup, pass loop, block_sum, scalar, decide, 4a, ctl store]")
-print(np.median(rows, axis=0), "total", np.median(rows.sum(axis=1)))
+d = lambda a, b: np.median((rows[:, b] - rows[:, a]) * 10.0)
+print("ns: ctl+plan load %.0f | to end of block_sum %.0f | param entries+par' %.0f | decide %.0f | hot-path end %.0f" %
+      (d(0, 1), d(1, 3), d(3, 4), d(4, 5), d(5, 6)))
