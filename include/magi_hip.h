@@ -179,6 +179,13 @@ int magi_time_gradient(magi_handle* h, int n_chains, int reps, double* total_ms_
  * (DESIGN.md section 4.1). */
 int magi_gradient_bytes(magi_handle* h, int n_chains, double* phase_bytes);
 
+/* Diagnostics: per-class device time of the last magi_build_matrices when the environment variable
+ * MAGI_BUILD_PROFILE is set (HIP events around every launch; the build is serialised while profiling).
+ * Classes, in order: matern, diag-block Cholesky+inverse, potrf panel, potrf trailing SYRK, trtri,
+ * T^T T, m / K products, single-phase operators.  flops = fp64 operations actually issued.  Returns the
+ * number of classes (8); arrays must hold at least that many entries. */
+int magi_build_profile(magi_handle* h, double* flops, double* ms, int64_t* calls);
+
 /* Diagnostics: the 64-double transformed-parameter block of a chain (softplus / sigmoid / log
  * terms of the state in flight; in a -DMAGI_TAIL_STAMPS build entries 40.. hold timing stamps). */
 int magi_debug_par(magi_handle* h, int chain, double* out64);

@@ -17,6 +17,9 @@
 //     d/ds        = -A c sgn(s-t) u^nu K_{nu-1}(u)
 //     d2/dsdt     = A c^2 u^{nu-1} (K_{nu-1}(u) - u K_{nu-2}(u)),   u = c|s-t|, c = sqrt(2nu)/phi2,
 // which agree with the reference's kvp-based expressions (:790-815) to their own rounding error.
+#include <algorithm>
+#include <cstdlib>
+
 #include "magi_internal.h"
 
 namespace {
@@ -156,8 +159,7 @@ __global__ __launch_bounds__(256) void k_matern(MaternArgs a) {
 // fp64 MFMA GEMM:  C(m,n) = alpha * sum_k A(m,k) B(n,k) + beta * C(m,n)
 //   A(m,k) = A[m*sAm + k*sAk],  B(n,k) = B[n*sBn + k*sBk]  (arbitrary strides -> NN / NT / TN)
 //   128 x 128 tile per 256-thread workgroup, 4 waves x (64 x 64) = 4x4 v_mfma_f64_16x16x4_f64
-//   blocks each, K step 16, operands staged in LDS as [k][m] with pitch 144 doubles so the four
-//   k-rows a wave reads per MFMA fall on disjoint banks.
+//   blocks each, K step 16, operands staged in LDS as [k][m] with an odd pitch (129 doubles).
 // =============================================================================================
 using d4 = __attribute__((ext_vector_type(4))) double;
 
@@ -169,11 +171,11 @@ struct GemmArgs {
     double alpha, beta;
     int lower_only;    // 1: skip tiles strictly above the block diagonal (m0 + 127 < n0)
     int kmode;         // 0: k in [0, K) ; 1: k >= min-aligned max(m0, n0) (A, B "lower" in (k, m)) ;
-                       // 2: k < m0 + 128 (A lower-triangular in (m, k))
+                       // 2: k < m0 + 128 (A lower-triangular in (m, k)) ; 3: k >= n0 (B(n,k) zero for k < n)
     long batchA, batchB, batchC;   // element strides between grid.z batches
 };
 
-constexpr int GT = 128, GK = 16, GP = 144;
+constexpr int GT = 128, GK = 16, GP = 129;   // odd pitch: the k-fast staging stores of a 16-lane group hit 16 distinct bank pairs
 
 __device__ inline void gemm_load_tile(const double* base, long sm, long sk, int m0, int k0, int Mlim, int Klim, double (&reg)[8]) {
     // 128 x 16 tile = 2048 doubles, 8 per thread; walk the unit-stride dimension fastest
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(256) void k_gemm_f64(GemmArgs g) {
     int kbeg = 0, kend = g.K;
     if (g.kmode == 1) kbeg = (max(m0, n0) / GK) * GK;
     else if (g.kmode == 2) kend = min(g.K, m0 + GT);
+    else if (g.kmode == 3) kbeg = (n0 / GK) * GK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int lr = lane & 15, lk = lane >> 4;
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(256) void k_gemm_f64(GemmArgs g) {
 // diagonal block: Cholesky of an n x n (n <= 128) SPD block + explicit inverse of its factor.
 // Packed lower-triangular storage in LDS: 2 x 66 KB.
 // =============================================================================================
-__device__ inline int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+__device__ inline int tri(int i, int j) { return ((i * (i + 1)) >> 1) + j; }
 
 __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int n, double* Linv /* [128][128] */, int* status, int block_row0) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -297,6 +300,7 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
         __syncthreads();
         for (int i = k + 1 + ty; i < n; i += 16) {
             const double lik = L[tri(i, k)];
+#pragma unroll 4
             for (int j = k + 1 + tx; j <= i; j += 16) L[tri(i, j)] -= lik * L[tri(j, k)];
         }
         __syncthreads();
@@ -305,14 +309,28 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
         if (tid == 0) atomicCAS(status, -1, block_row0 + bad);
         return;
     }
-    // inverse, one column per thread (forward substitution), columns are independent
-    if (tid < n) {
-        const int j = tid;
-        X[tri(j, j)] = 1.0 / L[tri(j, j)];
-        for (int i = j + 1; i < n; ++i) {
+    // inverse by forward substitution: columns are independent; two adjacent lanes share a column and
+    // split the inner sum (even / odd k), combined with one DPP-free shuffle
+    {
+        const int j = tid >> 1, half = tid & 1;
+        if (j < n && half == 0) X[tri(j, j)] = 1.0 / L[tri(j, j)];
+        for (int i = 1; i < n; ++i) {
+            const int ro = (i * (i + 1)) >> 1;
             double s = 0.0;
-            for (int k = j; k < i; ++k) s = fma(L[tri(i, k)], X[tri(k, j)], s);
-            X[tri(i, j)] = -s / L[tri(i, i)];
+            if (j < i && j < n) {
+                double s1 = 0.0;
+#pragma unroll 4
+                for (int k = j + half; k < i; k += 4) {
+                    s = fma(L[ro + k], X[tri(k, j)], s);
+                    if (k + 2 < i) s1 = fma(L[ro + k + 2], X[tri(k + 2, j)], s1);
+                }
+                s += s1;
+            }
+            s += __shfl_xor(s, 1, 64);
+            if (j < i && j < n && half == 0) X[ro + j] = -s / L[ro + i];
+            // the next row reads X[i][j] written by the partner lane of the same wave only -> wave-level order suffices,
+            // but columns of different waves never interact, so no block barrier is needed
+            __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
@@ -358,12 +376,45 @@ struct Linalg {
     int* status = nullptr;
 };
 
-int launch_gemm(magi_handle* h, hipStream_t s, const GemmArgs& g, int batch = 1) {
+// optional per-class timing of the build (MAGI_BUILD_PROFILE=1): HIP events around every launch, so the
+// build is serialised and slower -- diagnostics only
+enum BuildClass { BC_MATERN = 0, BC_DIAG, BC_PANEL, BC_TRAIL, BC_TRTRI, BC_LAUUM, BC_PROD, BC_FUSED, BC_COUNT };
+struct BuildProfile { double flops[BC_COUNT]; double ms[BC_COUNT]; long calls[BC_COUNT]; bool on; hipEvent_t e0, e1; };
+BuildProfile g_prof{};
+
+void prof_begin(hipStream_t s) { if (g_prof.on) (void)hipEventRecord(g_prof.e0, s); }
+void prof_end(hipStream_t s, int cls, double flops) {
+    if (!g_prof.on) return;
+    (void)hipEventRecord(g_prof.e1, s);
+    (void)hipEventSynchronize(g_prof.e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, g_prof.e0, g_prof.e1);
+    g_prof.ms[cls] += ms; g_prof.flops[cls] += flops; g_prof.calls[cls] += 1;
+}
+
+// executed flops of a launch: tiles actually computed x 2 * 128 * 128 * (k range)
+double gemm_flops(const GemmArgs& g, int batch) {
+    double f = 0.0;
+    for (int m0 = 0; m0 < g.M; m0 += GT)
+        for (int n0 = 0; n0 < g.N; n0 += GT) {
+            if (g.lower_only && m0 + GT - 1 < n0) continue;
+            int kb = 0, ke = g.K;
+            if (g.kmode == 1) kb = (std::max(m0, n0) / GK) * GK;
+            else if (g.kmode == 2) ke = std::min(g.K, m0 + GT);
+            else if (g.kmode == 3) kb = (n0 / GK) * GK;
+            f += 2.0 * std::min(GT, g.M - m0) * std::min(GT, g.N - n0) * std::max(0, ke - kb);
+        }
+    return f * batch;
+}
+
+int launch_gemm(magi_handle* h, hipStream_t s, const GemmArgs& g, int batch = 1, int cls = BC_PROD) {
     if (g.M <= 0 || g.N <= 0) return MAGI_OK;
     dim3 grid((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, batch);
+    prof_begin(s);
     hipLaunchKernelGGL(k_gemm_f64, grid, dim3(256), 0, s, g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("gemm launch: ") + hipGetErrorString(e));
+    if (g_prof.on) prof_end(s, cls, gemm_flops(g, batch));
     return MAGI_OK;
 }
 
@@ -379,7 +430,9 @@ int potrf(Linalg& la, double* A, const char* what) {
     for (int j0 = 0, jb = 0; j0 < N; j0 += NB, ++jb) {
         const int n = std::min(NB, N - j0);
         double* Ajj = A + (size_t)j0 * N + j0;
+        prof_begin(la.s);
         hipLaunchKernelGGL(k_diag_chol_inv, dim3(1), dim3(256), lds, la.s, Ajj, (long)N, n, la.dinv + (size_t)jb * 128 * 128, la.status, j0);
+        prof_end(la.s, BC_DIAG, (double)n * n * n);        // n^3/3 factor + 2 n^3/3 inverse
         const int M = N - j0 - n;
         if (M <= 0) break;
         double* P = A + (size_t)(j0 + n) * N + j0;       // panel below the diagonal block
@@ -388,7 +441,7 @@ int potrf(Linalg& la, double* A, const char* what) {
         g.A = P; g.sAm = N; g.sAk = 1;
         g.B = la.dinv + (size_t)jb * 128 * 128; g.sBn = 128; g.sBk = 1;
         g.C = P; g.ldc = N; g.M = M; g.N = n; g.K = n; g.alpha = 1.0; g.beta = 0.0;
-        int rc = launch_gemm(h, la.s, g);
+        int rc = launch_gemm(h, la.s, g, 1, BC_PANEL);
         if (rc) return rc;
         // trailing (lower tiles): A22 <- A22 - P P^T
         GemmArgs t{};
@@ -396,7 +449,7 @@ int potrf(Linalg& la, double* A, const char* what) {
         t.B = P; t.sBn = N; t.sBk = 1;
         t.C = A + (size_t)(j0 + n) * N + (j0 + n); t.ldc = N; t.M = M; t.N = M; t.K = n; t.alpha = -1.0; t.beta = 1.0;
         t.lower_only = 1;
-        if ((rc = launch_gemm(h, la.s, t))) return rc;
+        if ((rc = launch_gemm(h, la.s, t, 1, BC_TRAIL))) return rc;
     }
     int st = -1;
     MAGI_HIP_CHECK(h, hipMemcpyAsync(&st, la.status, sizeof(int), hipMemcpyDeviceToHost, la.s));
@@ -406,33 +459,43 @@ int potrf(Linalg& la, double* A, const char* what) {
     return MAGI_OK;
 }
 
-// In-place T = L^-1 (lower) from the factor left by potrf, block columns from last to first:
-//   T_jj = Dinv_j ;  T[j+1:, j] = -T[j+1:, j+1:] (L[j+1:, j] Dinv_j)
+// In-place T = L^-1 (lower) from the factor left by potrf, bottom-up over block sizes s = 128, 256, ...:
+//   [T11 0; T21 T22] with T21 = -T22 (L21 T11).  Every level is two batched MFMA GEMMs over all block
+//   pairs, so the large levels expose (s/128)^2 x pairs tiles instead of the N/128 of a column sweep
+//   (measured at N=8192: 429 ms -> see profiles/).  The diagonal 128-blocks come from k_diag_chol_inv.
 int trtri(Linalg& la, double* A) {
     magi_handle* h = la.h;
     const int N = la.N, NB = 128;
     const int nb = (N + NB - 1) / NB;
-    for (int jb = nb - 1; jb >= 0; --jb) {
+    for (int jb = 0; jb < nb; ++jb) {
         const int j0 = jb * NB, n = std::min(NB, N - j0);
-        const int M = N - j0 - n;
-        double* Dj = la.dinv + (size_t)jb * 128 * 128;
-        if (M > 0) {
-            double* Lp = A + (size_t)(j0 + n) * N + j0;
-            GemmArgs g{};   // panel <- L[j+1:, j] * Dinv_j           (NN: B(n,k) = Dj[k][n])
-            g.A = Lp; g.sAm = N; g.sAk = 1;
-            g.B = Dj; g.sBn = 1; g.sBk = 128;
-            g.C = la.panel; g.ldc = 128; g.M = M; g.N = n; g.K = n; g.alpha = 1.0; g.beta = 0.0;
-            int rc = launch_gemm(h, la.s, g);
+        MAGI_HIP_CHECK(h, hipMemcpy2DAsync(A + (size_t)j0 * N + j0, (size_t)N * sizeof(double), la.dinv + (size_t)jb * 128 * 128,
+                                           128 * sizeof(double), (size_t)n * sizeof(double), n, hipMemcpyDeviceToDevice, la.s));
+    }
+    for (long s = NB; s < N; s *= 2) {
+        const int nfull = (int)(N / (2 * s));
+        const long rem = N - (long)nfull * 2 * s;            // rows left after the full pairs
+        for (int pass = 0; pass < 2; ++pass) {
+            int batch; long b0; int M2;
+            if (pass == 0) { batch = nfull; b0 = 0; M2 = (int)s; }
+            else { batch = (rem > s) ? 1 : 0; b0 = (long)nfull * 2 * s; M2 = (int)(rem - s); }
+            if (batch <= 0) continue;
+            const long pstride = 2 * s * ((long)N + 1);
+            double* base = A + b0 * ((long)N + 1);
+            GemmArgs g{};   // tmp <- L21 T11                 (T11 lower: B(n,k) = T11[k][n] = 0 for k < n)
+            g.A = base + s * N; g.sAm = N; g.sAk = 1;
+            g.B = base; g.sBn = 1; g.sBk = N;
+            g.C = la.panel; g.ldc = s; g.M = M2; g.N = (int)s; g.K = (int)s; g.alpha = 1.0; g.beta = 0.0; g.kmode = 3;
+            g.batchA = pstride; g.batchB = pstride; g.batchC = s * s;
+            int rc = launch_gemm(h, la.s, g, batch, BC_TRTRI);
             if (rc) return rc;
-            GemmArgs t{};   // T[j+1:, j] <- -T22 * panel             (T22 lower triangular: k < m0 + 128)
-            t.A = A + (size_t)(j0 + n) * N + (j0 + n); t.sAm = N; t.sAk = 1;
-            t.B = la.panel; t.sBn = 1; t.sBk = 128;
-            t.C = Lp; t.ldc = N; t.M = M; t.N = n; t.K = M; t.alpha = -1.0; t.beta = 0.0; t.kmode = 2;
-            if ((rc = launch_gemm(h, la.s, t))) return rc;
+            GemmArgs t{};   // T21 <- -T22 tmp                 (T22 lower: k < m0 + 128)
+            t.A = base + s * N + s; t.sAm = N; t.sAk = 1;
+            t.B = la.panel; t.sBn = 1; t.sBk = s;
+            t.C = base + s * N; t.ldc = N; t.M = M2; t.N = (int)s; t.K = M2; t.alpha = -1.0; t.beta = 0.0; t.kmode = 2;
+            t.batchA = pstride; t.batchB = s * s; t.batchC = pstride;
+            if ((rc = launch_gemm(h, la.s, t, batch, BC_TRTRI))) return rc;
         }
-        // T_jj = Dinv_j (rows beyond n are zero-padded in Dinv)
-        MAGI_HIP_CHECK(h, hipMemcpy2DAsync(A + (size_t)j0 * N + j0, (size_t)N * sizeof(double), Dj, 128 * sizeof(double),
-                                           (size_t)n * sizeof(double), n, hipMemcpyDeviceToDevice, la.s));
     }
     return MAGI_OK;
 }
@@ -445,7 +508,7 @@ int lauum_tt(Linalg& la, const double* T, double* out) {
     g.B = T; g.sBn = 1; g.sBk = N;      // B(n,k) = T[k][n]
     g.C = out; g.ldc = N; g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 0.0;
     g.lower_only = 1; g.kmode = 1;
-    int rc = launch_gemm(la.h, la.s, g);
+    int rc = launch_gemm(la.h, la.s, g, 1, BC_LAUUM);
     if (rc) return rc;
     dim3 grid((N + 31) / 32, (N + 31) / 32);
     hipLaunchKernelGGL(k_mirror_lower, grid, dim3(32, 32), 0, la.s, out, N);
@@ -464,7 +527,7 @@ int linalg_init(Linalg& la, magi_handle* h, int N) {
     la.h = h; la.s = h->stream; la.N = N;
     const int nb = (N + 127) / 128;
     MAGI_HIP_CHECK(h, hipMalloc(&la.dinv, (size_t)nb * 128 * 128 * sizeof(double)));
-    MAGI_HIP_CHECK(h, hipMalloc(&la.panel, (size_t)N * 128 * sizeof(double)));
+    MAGI_HIP_CHECK(h, hipMalloc(&la.panel, std::max((size_t)N * 128, (size_t)N * N / 2 + 128 * 128) * sizeof(double)));
     MAGI_HIP_CHECK(h, hipMalloc(&la.status, sizeof(int)));
     MAGI_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_diag_chol_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (128 * 129 / 2) + 2) * (int)sizeof(double)));
     return MAGI_OK;
@@ -506,7 +569,9 @@ int launch_matern(magi_handle* h, const double* dI, int N, double phi1, double p
     a.diag_pp = nu * phi1 / ((phi2 * phi2) * (nu - 1.0));
     a.bc = bessel_consts(nu);
     dim3 grid((N + 63) / 64, (N + 63) / 64);
+    prof_begin(h->stream);
     hipLaunchKernelGGL(k_matern, grid, dim3(256), 0, h->stream, a);
+    prof_end(h->stream, BC_MATERN, 0.0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("matern launch: ") + hipGetErrorString(e));
     return MAGI_OK;
@@ -527,14 +592,14 @@ int magi_fused_operators(magi_handle* h, int N, int D, double* dCs_inout_H, cons
     g.B = dM; g.sBn = 1; g.sBk = N;
     g.C = dE; g.ldc = N; g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 0.0;
     g.batchA = nn; g.batchB = nn; g.batchC = nn;
-    int rc = launch_gemm(h, h->stream, g, D);
+    int rc = launch_gemm(h, h->stream, g, D, BC_FUSED);
     if (rc) return rc;
     GemmArgs t{};     // H = M^T E + Cs
     t.A = dM; t.sAm = 1; t.sAk = N;
     t.B = dE; t.sBn = 1; t.sBk = N;
     t.C = dCs_inout_H; t.ldc = N; t.M = N; t.N = N; t.K = N; t.alpha = 1.0; t.beta = 1.0;
     t.batchA = nn; t.batchB = nn; t.batchC = nn;
-    return launch_gemm(h, h->stream, t, D);
+    return launch_gemm(h, h->stream, t, D, BC_FUSED);
 }
 
 int magi_matern_blocks_device(magi_handle* h, const double* I, int N, double phi1, double phi2, double nu, double* Kappa,
@@ -556,8 +621,18 @@ int magi_matern_blocks_device(magi_handle* h, const double* I, int N, double phi
     return MAGI_OK;
 }
 
+int magi_build_profile_get(double* flops, double* ms, long* calls) {
+    for (int i = 0; i < BC_COUNT; ++i) { flops[i] = g_prof.flops[i]; ms[i] = g_prof.ms[i]; calls[i] = g_prof.calls[i]; }
+    return BC_COUNT;
+}
+
 int magi_build_matrices_device(magi_handle* h, const double* I, int N, int D, const double* phi1, const double* phi2,
                                double nu, int bandsize, double* C_inv, double* m, double* K_inv) {
+    g_prof.on = getenv("MAGI_BUILD_PROFILE") != nullptr;
+    if (g_prof.on) {
+        if (!g_prof.e0) { (void)hipEventCreate(&g_prof.e0); (void)hipEventCreate(&g_prof.e1); }
+        for (int i = 0; i < BC_COUNT; ++i) { g_prof.flops[i] = 0.0; g_prof.ms[i] = 0.0; g_prof.calls[i] = 0; }
+    }
     for (int d = 0; d < D; ++d)
         if (!(phi1[d] > 0.0) || !(phi2[d] > 0.0)) return magi_fail(h, MAGI_E_BADARG, "phi1 and phi2 must be positive");
     const size_t nn = (size_t)N * N;

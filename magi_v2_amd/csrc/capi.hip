@@ -539,6 +539,14 @@ int magi_sample(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains, const
     return magi_sampler_get_samples(h, X_samps, sig_pre_samps, th_pre_samps);
 }
 
+int magi_build_profile(magi_handle* h, double* flops, double* ms, int64_t* calls) {
+    if (!h || !flops || !ms || !calls) return MAGI_E_BADARG;
+    long c[16];
+    const int n = magi_build_profile_get(flops, ms, c);
+    for (int i = 0; i < n; ++i) calls[i] = c[i];
+    return n;
+}
+
 int magi_debug_par(magi_handle* h, int chain, double* out64) {
     if (!h || !out64 || chain < 0 || chain >= h->n_chains) return MAGI_E_BADARG;
     (void)hipSetDevice(h->device);

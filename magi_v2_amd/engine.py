@@ -59,6 +59,7 @@ _SYMBOLS = {
     "magi_time_gradient": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp]),
     "magi_gradient_bytes": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "magi_debug_par": (C.c_int, [C.c_void_p, C.c_int, _dp]),
+    "magi_build_profile": (C.c_int, [C.c_void_p, _dp, _dp, _lp]),
 }
 
 _lib = None
@@ -274,6 +275,16 @@ class MagiEngine:
         ph = np.zeros(6)
         self._check(self._lib.magi_time_gradient(self._h, int(n_chains), int(reps), C.byref(total), _ptr(ph)))
         return total.value, ph
+
+    BUILD_CLASSES = ("matern", "diag_chol_inv", "potrf_panel", "potrf_trailing_syrk", "trtri", "TtT", "m_K_products",
+                     "single_phase_operators")
+
+    def build_profile(self):
+        """Per-class (flops, ms, calls) of the last build_matrices run under MAGI_BUILD_PROFILE=1."""
+        f, ms = np.zeros(16), np.zeros(16)
+        calls = np.zeros(16, dtype=np.int64)
+        n = self._lib.magi_build_profile(self._h, _ptr(f), _ptr(ms), calls.ctypes.data_as(_lp))
+        return {self.BUILD_CLASSES[i]: (f[i], ms[i], int(calls[i])) for i in range(n)}
 
     def debug_par(self, chain=0):
         out = np.zeros(64)
