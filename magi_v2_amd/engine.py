@@ -70,7 +70,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("MAGI_HIP_LIB") or LIB_PATH      # MAGI_HIP_LIB: A/B builds in one session
     if not os.path.exists(p):
         raise ImportError(f"{p} not found: build it with `python -m magi_v2_amd.build` (hipcc, gfx950); "
                           "magi_v2_amd has no CPU fallback")
