@@ -151,7 +151,9 @@ __device__ __forceinline__ void leap_service(const DevChains& ch, int c0) {
 }
 
 // ---- dense operators: grid (ceil(N / RI), ceil(n_chains / NC)), block 64 * D * RI -------------------
-template <int NC, int DRIFT>
+// FVEC: the drift of every chain's state has been stored by k_drift (V_F) -- used when several chains share
+// the matrix stream, where re-evaluating the drift for every matrix row (N-fold redundant) would dominate
+template <int NC, int DRIFT, bool FVEC>
 __global__ __launch_bounds__(64 * DriftT<DRIFT>::D * LEAP_RI) void k_leap_dense(DevProblem pb, DevChains ch) {
     using DR = DriftT<DRIFT>;
     constexpr int D = DR::D, P = DR::P;
@@ -172,13 +174,15 @@ __global__ __launch_bounds__(64 * DriftT<DRIFT>::D * LEAP_RI) void k_leap_dense(
     const double mud = pb.mu[d];
 
     const double* qc[NC];
+    const double* fc[NC];
     double th[NC][P];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int cc = min(c0 + c, ch.n_chains - 1);
         qc[c] = ch.vec + vec_off(pb, cc, V_Q + ch.plan[cc].cur);
+        fc[c] = ch.vec + vec_off(pb, cc, V_F) + (size_t)d * N;
 #pragma unroll
-        for (int k = 0; k < P; ++k) th[c][k] = ch.par[(size_t)cc * PAR_COUNT + PAR_TH + k];
+        for (int k = 0; k < P; ++k) th[c][k] = FVEC ? 0.0 : ch.par[(size_t)cc * PAR_COUNT + PAR_TH + k];
     }
     double ah[NC], ae[NC], at[NC], ak[NC];
 #pragma unroll
@@ -191,6 +195,15 @@ __global__ __launch_bounds__(64 * DriftT<DRIFT>::D * LEAP_RI) void k_leap_dense(
         const int j0 = 2 * jj, j1 = min(2 * jj + 1, N - 1);     // ld is N rounded up to even: the pad column is zero
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
+            if (FVEC) {
+                const double xca = qc[c][d * N + j0] - mud, xcb = qc[c][d * N + j1] - mud;
+                const double fa = fc[c][j0], fb = fc[c][j1];
+                ah[c] = fma(h.x, xca, ah[c]); ah[c] = fma(h.y, xcb, ah[c]);
+                ae[c] = fma(e.x, xca, ae[c]); ae[c] = fma(e.y, xcb, ae[c]);
+                at[c] = fma(t.x, fa, at[c]); at[c] = fma(t.y, fb, at[c]);
+                ak[c] = fma(k.x, fa, ak[c]); ak[c] = fma(k.y, fb, ak[c]);
+                continue;
+            }
             double xa[D], xb[D];
 #pragma unroll
             for (int dd = 0; dd < D; ++dd) { xa[dd] = qc[c][dd * N + j0]; xb[dd] = qc[c][dd * N + j1]; }
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(64 * DriftT<DRIFT>::D * LEAP_RI) void k_leap_dense(
 }
 
 // ---- banded operators: rows hold columns [i - bf, i + bf] ---------------------------------------------
-template <int NC, int DRIFT>
+template <int NC, int DRIFT, bool FVEC>
 __global__ __launch_bounds__(64 * DriftT<DRIFT>::D * LEAP_RI) void k_leap_band(DevProblem pb, DevChains ch) {
     using DR = DriftT<DRIFT>;
     constexpr int D = DR::D, P = DR::P;
@@ -226,13 +239,15 @@ __global__ __launch_bounds__(64 * DriftT<DRIFT>::D * LEAP_RI) void k_leap_band(D
     const double *ph = pb.FH + ro, *pe = pb.FE + ro, *pt = pb.FEt + ro, *pk = pb.FK + ro;
     const double mud = pb.mu[d];
     const double* qc[NC];
+    const double* fc[NC];
     double th[NC][P];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int cc = min(c0 + c, ch.n_chains - 1);
         qc[c] = ch.vec + vec_off(pb, cc, V_Q + ch.plan[cc].cur);
+        fc[c] = ch.vec + vec_off(pb, cc, V_F) + (size_t)d * N;
 #pragma unroll
-        for (int k = 0; k < P; ++k) th[c][k] = ch.par[(size_t)cc * PAR_COUNT + PAR_TH + k];
+        for (int k = 0; k < P; ++k) th[c][k] = FVEC ? 0.0 : ch.par[(size_t)cc * PAR_COUNT + PAR_TH + k];
     }
     double ah[NC], ae[NC], at[NC], ak[NC];
 #pragma unroll
@@ -245,6 +260,12 @@ __global__ __launch_bounds__(64 * DriftT<DRIFT>::D * LEAP_RI) void k_leap_band(D
         const double h = in ? ph[kk] : 0.0, e = in ? pe[kk] : 0.0, t = in ? pt[kk] : 0.0, k = in ? pk[kk] : 0.0;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
+            if (FVEC) {
+                const double xc = qc[c][d * N + jc] - mud, fa = fc[c][jc];
+                ah[c] = fma(h, xc, ah[c]); ae[c] = fma(e, xc, ae[c]);
+                at[c] = fma(t, fa, at[c]); ak[c] = fma(k, fa, ak[c]);
+                continue;
+            }
             double xa[D];
 #pragma unroll
             for (int dd = 0; dd < D; ++dd) xa[dd] = qc[c][dd * N + jc];
@@ -258,6 +279,26 @@ __global__ __launch_bounds__(64 * DriftT<DRIFT>::D * LEAP_RI) void k_leap_band(D
         }
     }
     leap_epilogue<NC, DRIFT>(pb, ch, c0, ri, d, lane, ah, ae, at, ak, res, redk);
+}
+
+// f(X, theta) of every active chain's evaluated state -> V_F (only launched when n_chains > 1)
+template <int DRIFT>
+__global__ __launch_bounds__(256) void k_drift(DevProblem pb, DevChains ch) {
+    using DR = DriftT<DRIFT>;
+    if (ch.gctl->all_done) return;
+    const int c = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const LeafPlan lp = ch.plan[c];
+    if (!lp.active || i >= pb.N) return;
+    const double* q = ch.vec + vec_off(pb, c, V_Q + lp.cur);
+    double* F = ch.vec + vec_off(pb, c, V_F);
+    double x[DR::D], th[DR::P], f[DR::D];
+#pragma unroll
+    for (int d = 0; d < DR::D; ++d) x[d] = q[d * pb.N + i];
+#pragma unroll
+    for (int k = 0; k < DR::P; ++k) th[k] = ch.par[(size_t)c * PAR_COUNT + PAR_TH + k];
+    DR::f(x, th, f);
+#pragma unroll
+    for (int d = 0; d < DR::D; ++d) F[d * pb.N + i] = f[d];
 }
 
 // validation / bootstrap plan: evaluate buffer 0, no leapfrog
@@ -291,8 +332,10 @@ int launch_leap_nd(magi_handle* h, int n_chains, hipStream_t s) {
     const DevProblem& pb = h->pb;
     const dim3 grid((pb.N + LEAP_RI - 1) / LEAP_RI + 1, (n_chains + NC - 1) / NC);      // + the service block
     const dim3 block(64 * DriftT<DRIFT>::D * LEAP_RI);
-    if (pb.bandf < 0) hipLaunchKernelGGL((k_leap_dense<NC, DRIFT>), grid, block, 0, s, pb, h->ch);
-    else hipLaunchKernelGGL((k_leap_band<NC, DRIFT>), grid, block, 0, s, pb, h->ch);
+    constexpr bool FVEC = NC > 1;
+    if (FVEC) hipLaunchKernelGGL((k_drift<DRIFT>), dim3((pb.N + 255) / 256, n_chains), dim3(256), 0, s, pb, h->ch);
+    if (pb.bandf < 0) hipLaunchKernelGGL((k_leap_dense<NC, DRIFT, FVEC>), grid, block, 0, s, pb, h->ch);
+    else hipLaunchKernelGGL((k_leap_band<NC, DRIFT, FVEC>), grid, block, 0, s, pb, h->ch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("leap launch: ") + hipGetErrorString(e));
     return MAGI_OK;
@@ -312,6 +355,7 @@ int launch_leap_nc(magi_handle* h, int n_chains, hipStream_t s) {
 int magi_leap_wgs(const DevProblem& pb) { return (pb.N + LEAP_RI - 1) / LEAP_RI; }
 
 int magi_launch_leap(magi_handle* h, int n_chains, hipStream_t s) {
+    if (n_chains >= 6) return launch_leap_nc<8>(h, n_chains, s);
     if (n_chains >= 3) return launch_leap_nc<4>(h, n_chains, s);
     if (n_chains == 2) return launch_leap_nc<2>(h, n_chains, s);
     return launch_leap_nc<1>(h, n_chains, s);

@@ -55,7 +55,8 @@ enum VecSlot {
     V_CX,        // Csym * xc           [D][N]
     V_R,         // f - m xc            [D][N]
     V_KR,        // Ksym * r            [D][N]   (fused path: Ksym * f)
-    V_ETF,       // fused path: FEt * f [D][N]   (V_CX holds FH * xc, V_R holds FE * xc)
+    V_ETF,       // (validation kernels only)
+    V_F,         // drift f(X, theta) of the evaluated state [D][N]; filled by k_drift when n_chains > 1
     V_PL, V_QL, V_GL,       // left end of the trajectory
     V_PR, V_QR, V_GR,       // right end
     V_CANDQ, V_CANDG,       // trajectory-level proposal
