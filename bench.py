@@ -133,6 +133,19 @@ def main():
 
     state = eng.sampler_state() if (world == 1 and not a.no_cpu_baseline) else None   # before the timing launches clobber it
 
+    # ---- fixed-L HMC (L = 32, step size from a 100-step dual-averaging warm-up), SURVEY 8d: reported next to NUTS ----
+    hcfg = eng.default_cfg(num_results=a.steps, num_burnin_steps=100, stale_cache=0, mode=1, hmc_leapfrogs=32)
+    eng.sampler_init(hcfg, rep(Xhat), rep(sig_pre0), rep(th_pre0), seed=a.seed, chain_ids=chain_ids)
+    eng.sampler_run(100)
+    torch.cuda.synchronize()
+    th0 = time.perf_counter()
+    hlf, _ = eng.sampler_run(a.steps)
+    torch.cuda.synchronize()
+    hmc_s = time.perf_counter() - th0
+    hd = eng.sampler_diag()
+    hmc = {"samples_per_s": round(cpg * a.steps / hmc_s, 2), "leapfrogs_per_s": round(hlf / hmc_s, 1), "L": 32,
+           "accept_rate": round(float(hd.is_accepted[:, 100:].mean()), 3), "step_size": float(hd.step_size[0, -1]), "scope": "rank 0"}
+
     # ---- roofline of the dominant kernel (phase-1 mat-vec), HIP events on the engine's stream -----------
     grad_ms, phase_ms = eng.time_gradient(cpg, 300)
     phase_bytes = eng.gradient_bytes(cpg)
@@ -190,7 +203,7 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu,
         "leapfrogs_per_s": round(lf_total / elapsed, 1), "us_per_leapfrog_slot": round(elapsed / (lf_total / n_chains) * 1e6, 2),
         "mean_tree_depth": round(float(post.mean()), 2), "device_ms": round(dev_ms, 2), "build_ms": round(build_ms, 1),
-        "gather_ms": round(gather_ms, 3), "theta_mean": [round(float(x), 4) for x in np.log1p(np.exp(th_all)).reshape(-1, P).mean(axis=0)],
+        "gather_ms": round(gather_ms, 3), "hmc_L32": hmc, "theta_mean": [round(float(x), 4) for x in np.log1p(np.exp(th_all)).reshape(-1, P).mean(axis=0)],
     }
     if cpu:
         out["speedup_vs_cpu_port"] = round(value / cpu["value"], 1)

@@ -326,7 +326,8 @@ int magi_sampler_init(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains,
         return magi_fail(h, MAGI_E_BADARG, "need num_results + num_burnin_steps > 0");
     if (cfg->max_tree_depth < 1 || cfg->max_tree_depth > MAGI_MAX_DEPTH)
         return magi_fail(h, MAGI_E_BADARG, "max_tree_depth must be in [1, 12]");
-    if (cfg->mode != MAGI_MODE_NUTS) return magi_fail(h, MAGI_E_BADARG, "only MAGI_MODE_NUTS is implemented");
+    if (cfg->mode != MAGI_MODE_NUTS && cfg->mode != MAGI_MODE_HMC) return magi_fail(h, MAGI_E_BADARG, "unknown sampler mode");
+    if (cfg->mode == MAGI_MODE_HMC && cfg->hmc_leapfrogs < 1) return magi_fail(h, MAGI_E_BADARG, "hmc_leapfrogs must be >= 1");
     if (!(cfg->step_size > 0.0)) return magi_fail(h, MAGI_E_BADARG, "step_size must be positive");
     (void)hipSetDevice(h->device);
     int rc = magi_ensure_chains(h, n_chains);

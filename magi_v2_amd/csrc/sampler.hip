@@ -67,16 +67,16 @@ __device__ __noinline__ void dual_averaging_eval(double target_accept, int n_ada
 }
 
 // plan of the leaf with index c.it of the current subtree (evaluated from buffer c.cur)
-__device__ __forceinline__ LeafPlan make_leaf_plan(const ChainCtl& c, unsigned long long seed) {
+__device__ __forceinline__ LeafPlan make_leaf_plan(const ChainCtl& c, unsigned long long seed, bool hmc) {
     LeafPlan p{};
     p.active = 1;
     p.leaf = 1;
     p.cur = c.cur;
     const int it = c.it;
-    p.even = ((it & 1) == 0) ? 1 : 0;
+    p.even = (!hmc && (it & 1) == 0) ? 1 : 0;
     p.ck_slot = __popc((unsigned)it);
     int nk = 0;
-    if (!p.even)
+    if (!hmc && (it & 1) != 0)
         for (int kk = 1; ((it + 1) & ((1 << kk) - 1)) == 0 && (1 << kk) <= c.nsteps; ++kk) nk = kk;
     p.nchk = min(nk, 4);
 #pragma unroll
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
     const size_t sv = pb.dimp;
 
     bool do_sample = false, do_doubling = false;     // what to set up before returning
+    const bool hmc = cfg.mode == MAGI_MODE_HMC;       // fixed-L HMC: one forward "subtree" of L leaves, Metropolis at its end
 
     if (c.phase == PH_IDLE) {
         if (c.k < stop_k) {
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
             c.total_leapfrogs += 1;
             const int it = c.it;
             int nk = 0;
-            if (!lp.even)
+            if (!hmc && (it & 1) != 0)
                 for (int kk = 1; ((it + 1) & ((1 << kk) - 1)) == 0 && (1 << kk) <= c.nsteps; ++kk) nk = kk;
             bool no_u = true;
 #pragma unroll
@@ -180,11 +181,11 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
             __syncthreads();
             MAGI_STAMP(par, 5);
             const double wsum_leaf = shs[18];
-            const bool accept_leaf = (u_leaf <= ediff - wsum_leaf);
+            const bool accept_leaf = !hmc && (u_leaf <= ediff - wsum_leaf);
             c.leaf_ctr += 1;
             if (accept_leaf) { c.sub_L = L; c.sub_energy = energy; }
             c.sub_weight = wsum_leaf;
-            const bool cont_tree = not_divergent && (c.cont != 0);
+            const bool cont_tree = hmc || (not_divergent && (c.cont != 0));
             c.cont = (no_u && cont_tree) ? 1 : 0;
             c.nd = (c.nd && not_divergent) ? 1 : 0;
             if (cont_tree) c.e_sum_sub += shs[19];
@@ -197,18 +198,19 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
                     for (int e = tid; e < dim; e += blockDim.x) { v.subq[e] = qcur[e]; v.subg[e] = v.g[e]; }
                 c.cur = lp.cur ^ 1;
                 if (tid == 0) {
-                    ch.plan[chain] = make_leaf_plan(c, cfg.seed);
+                    ch.plan[chain] = make_leaf_plan(c, cfg.seed, hmc);
                     ch.ctl[chain] = c;
                 }
                 MAGI_STAMP(par, 6);
                 return;
             }
 
-            // ---- subtree finished: merge into the trajectory (biased progressive sampling) ---------------
+            // ---- subtree finished: merge into the trajectory (biased progressive sampling); for HMC the
+            //      "subtree" is the whole trajectory and the merge is the Metropolis test on its last state ----
             const double tree_weight = c.cont ? c.sub_weight : -INFINITY;
-            if (tid == 0) shs[20] = logaddexp(tree_weight, c.cand_weight);
-            const double thresh = tree_weight - c.cand_weight;
-            const bool choose = (u_merge <= thresh) && (c.cont != 0);
+            if (tid == 0) shs[20] = hmc ? 0.0 : logaddexp(tree_weight, c.cand_weight);
+            const double thresh = hmc ? ediff : tree_weight - c.cand_weight;
+            const bool choose = (u_merge <= thresh) && (hmc ? not_divergent : (c.cont != 0));
             double* pe = (c.dir > 0) ? v.pR : v.pL;
             double* qe = (c.dir > 0) ? v.qR : v.qL;
             double* ge = (c.dir > 0) ? v.gR : v.gL;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
             for (int e = tid; e < dim; e += blockDim.x) {
                 const double qv = qcur[e], gv = v.g[e];
                 // the subtree proposal is this leaf if it was just accepted, else what V_SUB holds
-                const double sq = accept_leaf ? qv : v.subq[e], sg = accept_leaf ? gv : v.subg[e];
+                const double sq = (accept_leaf || hmc) ? qv : v.subq[e], sg = (accept_leaf || hmc) ? gv : v.subg[e];
                 if (choose) { v.candq[e] = sq; v.candg[e] = sg; }
                 const double pn = pleaf[e];
                 pe[e] = pn; qe[e] = qv; ge[e] = gv;
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
                 dots[1] = fma(rr, pn, dots[1]);
             }
             block_sum<2>(dots, sh);        // (its barriers publish shs[20])
+            if (hmc) { c.sub_L = L; c.sub_energy = energy; }
             if (choose) { c.cand_L = c.sub_L; c.cand_energy = c.sub_energy; c.cand_bfac = c.beta_k; c.is_accepted = 1; }
             c.cand_weight = shs[20];
             if (c.dir > 0) { c.LR = c.L_cur; c.bfacR = c.beta_k; } else { c.LL = c.L_cur; c.bfacL = c.beta_k; }
@@ -235,14 +238,15 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
             c.lf_count += c.sub_lf;
             c.not_div = c.nd;
             c.depth += 1;
-            const bool continue_tree = (c.cont != 0) && no_u_traj;
+            const bool continue_tree = !hmc && (c.cont != 0) && no_u_traj;
+            if (hmc) { c.e_sum = shs[19]; }          // acceptance statistic of HMC: min(1, exp(energy difference))
             if (c.depth < cfg.max_depth && continue_tree) {
                 do_doubling = true;
             } else {
                 // ---- transition finished ------------------------------------------------------------------
                 if (tid == 0)
                     dual_averaging_eval(cfg.target_accept, cfg.n_adapt, c.da_step, c.da_step_size, c.da_error_sum, c.da_log_avg,
-                                        c.da_log_shrink, c.e_sum, c.lf_count, &shs[0]);
+                                        c.da_log_shrink, c.e_sum, hmc ? 1 : c.lf_count, &shs[0]);
                 __syncthreads();
                 const int k = c.k;
                 if (tid == 0) {
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
         // ---- start a doubling from the end selected by the direction bit; first half/full step ----------
         // (leapfrog with identity mass: p_half = p + eps/2 * grad ; q' = q + eps * p_half)
         Philox4 r = philox4x32_10((unsigned)c.depth, (unsigned)c.k, (unsigned)c.chain_id, STREAM_DIRECTION, cfg.seed);
-        const bool fwd = (r.x & 1u) != 0;
+        const bool fwd = hmc || (r.x & 1u) != 0;
         c.dir = fwd ? 1 : -1;
         const double* pe = fwd ? v.pR : v.pL;
         const double* qe = fwd ? v.qR : v.qL;
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
             v.rhosub[e] = 0.0;
             if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par);
         }
-        c.nsteps = 1 << c.depth;
+        c.nsteps = hmc ? cfg.hmc_L : (1 << c.depth);
         c.it = 0;
         c.sub_weight = -INFINITY;
         c.e_sum_sub = 0.0;
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
         c.cont = 1;
         c.nd = c.not_div;
         c.phase = PH_LEAF;
-        if (tid == 0) ch.plan[chain] = make_leaf_plan(c, cfg.seed);
+        if (tid == 0) ch.plan[chain] = make_leaf_plan(c, cfg.seed, hmc);
     } else if (tid == 0) {
         LeafPlan off{};                  // idle after the bootstrap gradient
         ch.plan[chain] = off;

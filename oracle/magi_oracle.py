@@ -604,6 +604,36 @@ def nuts_one_step(q, cur_target, cur_grad, step_size, temp, fn_L, step, chain, k
                       energy=cand["energy"], target_log_prob=cand["target"])
 
 
+def hmc_one_step(q, cur_target, cur_grad, step_size, temp, fn_L, step, chain, key, num_leapfrog, max_energy_diff=1000.0) -> NutsResult:
+    """One fixed-length HMC transition (TFP ``HamiltonianMonteCarlo`` semantics: L leapfrogs forward,
+    Metropolis test on the end state), same caching / tempering conventions as ``nuts_one_step``.
+    Used for the fixed-L measurements of SURVEY 8d; shares the Philox streams with the HIP sampler."""
+    dim = q.shape[0]
+    p0 = rng_normal(dim, step, chain, key)
+    init_energy = cur_target - 0.5 * np.dot(p0, p0)
+    p, x, tgt, grd = p0, q, cur_target, cur_grad
+    Lx, gLx = None, None
+    for it in range(num_leapfrog):
+        p_half = p + 0.5 * step_size * grd
+        x = x + step_size * p_half
+        Lx, gLx = fn_L(x)
+        tgt, grd = temp * Lx, temp * gLx
+        p = p_half + 0.5 * step_size * grd
+    energy = tgt - 0.5 * np.dot(p, p)
+    if np.isnan(energy):
+        energy = -np.inf
+    ediff = energy - init_energy
+    not_divergent = bool(-ediff < max_energy_diff)
+    u = math.log1p(-rng_uniform(0, step, chain, STREAM_MERGE, key))
+    accept = bool(u <= ediff) and not_divergent
+    lar = min(ediff, 0.0) if np.isfinite(ediff) or ediff == -np.inf else -np.inf
+    if accept:
+        return NutsResult(q=x, L=Lx, gL=gLx, log_accept_ratio=lar, leapfrogs=num_leapfrog, depth=1, is_accepted=True,
+                          reach_max_depth=False, has_divergence=not not_divergent, energy=energy, target_log_prob=tgt)
+    return NutsResult(q=q, L=None, gL=None, log_accept_ratio=lar, leapfrogs=num_leapfrog, depth=1, is_accepted=False,
+                      reach_max_depth=False, has_divergence=not not_divergent, energy=init_energy, target_log_prob=cur_target)
+
+
 @dataclass
 class DualAveragingState:
     """TFP ``DualAveragingStepSizeAdaptationResults`` fields that evolve."""
@@ -667,7 +697,7 @@ def make_fn_L(pr: Problem):
 def sample_chain(pr: Problem, Xhat_init, sigma_sqs_init, thetas_init, num_results, num_burnin_steps,
                  seed: int, chain: int = 0, step_size: float = 0.1, target_accept_prob: float = 0.75,
                  max_tree_depth: int = 10, min_temp: float = 0.1, stale_cache: bool = True,
-                 anneal: bool = True, trace: Optional[list] = None):
+                 anneal: bool = True, trace: Optional[list] = None, hmc_leapfrogs: Optional[int] = None):
     """The reference's ``predict`` sampling loop (magi_v2.py:357-396) around ``LogAnnealedNUTS``
     (magi_v2.py:852-879): at chain step k the target is ``beta_temp(k) * L`` with
     ``beta_temp(k) = max(1/ln(k+2), min_temp)``; NUTS is wrapped in dual averaging for the first
@@ -690,8 +720,11 @@ def sample_chain(pr: Problem, Xhat_init, sigma_sqs_init, thetas_init, num_result
     for k in range(total):
         temp = temperature(k, min_temp) if anneal else 1.0
         tc = temp_prev if stale_cache else temp
-        res = nuts_one_step(q, tc * L, tc * gL, da.step_size, temp, fn_L, k, chain, seed,
-                            max_tree_depth=max_tree_depth)
+        if hmc_leapfrogs is None:
+            res = nuts_one_step(q, tc * L, tc * gL, da.step_size, temp, fn_L, k, chain, seed,
+                                max_tree_depth=max_tree_depth)
+        else:
+            res = hmc_one_step(q, tc * L, tc * gL, da.step_size, temp, fn_L, k, chain, seed, hmc_leapfrogs)
         ss_used = da.step_size
         if res.is_accepted:            # a new state was accepted somewhere in the tree
             q, L, gL = res.q, res.L, res.gL

@@ -117,3 +117,30 @@ def test_chain_moves_toward_the_true_seir_parameters():
     assert 0.5 < np.exp(np.minimum(d.log_accept_ratio[:, 150:], 0)).mean() <= 1.0
     # X trajectories stay near the data they are conditioned on
     assert np.abs(Xs.mean(axis=(0, 1)) - g["Xhat_init"]).max() < 0.1
+
+
+@pytest.mark.parametrize("L", [1, 7, 32])
+def test_fixed_length_hmc_matches_oracle(L):
+    """MAGI_MODE_HMC (fixed-L HMC next to NUTS): L leapfrogs forward + Metropolis, same Philox
+    streams, dual averaging on min(1, exp(dH)); compared with the oracle's hmc_one_step draw for draw."""
+    g = load_g4("seir4_N81")
+    pr = problem_from_g4(g, None)
+    eng = engine_for(pr, None)
+    theta0 = np.ones(pr.P)
+    X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], theta0, pr.LB)
+    burnin, results = 12, 6
+    cfg = eng.default_cfg(num_results=results, num_burnin_steps=burnin, mode=1, hmc_leapfrogs=L)
+    eng.sampler_init(cfg, X0, s0, t0, seed=77)
+    lf, _ = eng.sampler_run(burnin + results)
+    assert lf == L * (burnin + results)
+    Xs, sp, tp = eng.sampler_samples()
+    d = eng.sampler_diag()
+    trace = []
+    oX, osp, otp, info, _ = orc.sample_chain(pr, g["Xhat_init"], g["sigma_sqs_init"], theta0, results, burnin, seed=77,
+                                             trace=trace, hmc_leapfrogs=L)
+    np.testing.assert_array_equal(d.is_accepted[0], [int(r.is_accepted) for _, r, _ in trace])
+    np.testing.assert_array_equal(d.leapfrogs_taken[0], [L] * (burnin + results))
+    np.testing.assert_allclose(d.step_size[0], [s for _, _, s in trace], rtol=1e-8)
+    np.testing.assert_allclose(tp[0], otp, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(Xs[0], oX, rtol=0, atol=1e-8 * np.abs(oX).max())
+    eng.close()
