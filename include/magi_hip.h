@@ -66,6 +66,19 @@ int magi_build_matrices(magi_handle* h, const double* I, int N, int D,
                         const double* phi1, const double* phi2, double nu, int bandsize,
                         double* C_inv, double* m, double* K_inv);
 
+/* GP hyper-parameter fit: replaces MAGI_v2._fit_kernel_hparams (magi_v2.py:538-691) -- Adam (tf_keras defaults,
+ * `learning_rate`, `num_iters` steps) on the softplus-reparameterised (phi1, phi2, sigma^2) of every component,
+ * maximising  D * sum_d [ log N(x_d ; mu_d, phi1_d R_nu(phi2_d) + (sigma_d^2 + jitter) I) + TruncatedNormal priors ]
+ * with the reference's priors (magi_v2.py:611-627: loc 1e-4 / sigma_sq_loc / mu_phi2, scales 1000 sqrt(D) /
+ * 1000 sqrt(D) / sd_phi2 sqrt(D)).  X_filled[N][D] row-major (no NaN), mu[D] the GP means (magi_v2.py:559).
+ * phi1 / phi2 / sigma_sq hold the starting values on entry (magi_v2.py:631-639) and the fitted values on return.
+ * Every step is Matern assembly + Cholesky + inverse + trace terms on the GPU; loss_trace[num_iters] may be NULL.
+ * jitter: TFP's GaussianProcess default 1e-6. */
+int magi_fit_hparams(magi_handle* h, const double* I, int N, int D, const double* X_filled, const double* mu,
+                     const double* mu_phi2, const double* sd_phi2, const double* sigma_sq_loc, double nu,
+                     int num_iters, double learning_rate, double jitter,
+                     double* phi1, double* phi2, double* sigma_sq, double* loss_trace);
+
 /* The three Matern blocks alone (magi_v2.py:781-815) for one component; host outputs [N][N]. */
 int magi_matern_blocks(magi_handle* h, const double* I, int N, double phi1, double phi2, double nu,
                        double* Kappa, double* p_Kappa, double* Kappa_pp);

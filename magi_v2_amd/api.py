@@ -7,9 +7,9 @@ CPU implementation of that path in this package: without the library or a GPU th
 What differs from the reference, deliberately:
   * ``f_vec`` is a built-in drift name or a numpy-compatible callable that matches one
     (host.resolve_drift); TensorFlow is not a dependency.
-  * hyper-parameters: ``initial_fit`` uses the reference's *starting* values (var, Fourier prior
-    mean, (0.1 std)^2 -- magi_v2.py:631-639) unless ``hparams=`` is given; the TFP marginal
-    likelihood fit (magi_v2.py:538-691) is SURVEY.md section 8 row f1 (next).
+  * hyper-parameters are fitted on the GPU (``magi_fit_hparams``: the reference's GP marginal
+    likelihood + priors + Adam, magi_v2.py:538-691, restated -- TFP itself is not available, so this
+    step is parity-unpinned); ``hparams=`` / ``hparam_iters=0`` bypass it.
   * ``predict`` takes keyword-only extras (n_chains, seed, ...); defaults reproduce the reference.
 """
 from __future__ import annotations
@@ -113,9 +113,26 @@ class MAGI_v2:
             self._resident = fp
 
     # ------------------------------------------------------------------------------------------
+    def _fit_kernel_hparams(self, I, X_filled, verbose=False, num_iters: int = 1000):
+        """magi_v2.py:538-691 on the GPU (magi_fit_hparams): Adam x num_iters on the GP marginal likelihood +
+        the reference's Fourier-informed priors, starting from its initial values."""
+        pri = [host.fourier_phi2_prior(X_filled[:, d]) for d in range(X_filled.shape[1])]
+        init = host.hparams_initial(X_filled)
+        if verbose:
+            print(f"Fitting hparams for {X_filled.shape[1]} components on the GPU ({num_iters} Adam steps) ...")
+        return self.engine.fit_hparams(I, X_filled, X_filled.mean(axis=0), [p[0] for p in pri], [p[1] for p in pri],
+                                       init["sigma_sqs"], init["phi1s"], init["phi2s"], init["sigma_sqs"], num_iters=num_iters)
+
     def initial_fit(self, discretization: int, verbose=False, hparams: Optional[dict] = None,
-                    theta_init_iters: int = 10000):
-        """magi_v2.py:82-277.  ``hparams`` may carry phi1s / phi2s / sigma_sqs (observed components)."""
+                    theta_init_iters: int = 10000, hparam_iters: int = 1000, hparam_fit_on: str = "grid"):
+        """magi_v2.py:82-277.  Hyper-parameters are fitted as in the reference (1000 Adam steps on the
+        linearly interpolated discretisation grid, magi_v2.py:105-106) unless ``hparams`` carries phi1s /
+        phi2s / sigma_sqs for the observed components, or ``hparam_iters=0`` keeps the reference's starting
+        values.  ``hparam_fit_on="observed"`` is a documented deviation: it fits on the observation times only.
+        The inserted grid points are exact linear interpolants, which a GP marginal likelihood can only explain
+        with a short length scale and near-zero noise; on the vignette data that optimum (phi2 ~ 0.1,
+        sigma ~ 0.002) ruins the parameter recovery (theta ~ 1.5 instead of 6), while the fit on the observed
+        rows lands at the true noise level and recovers theta = (5.9, 0.56, 1.75) -- see DESIGN.md section 8."""
         self.I, self.X_obs_discret = host.discretize(self.ts_obs, self.X_obs, discretization)
         self.mag_I = self.I.shape[0]
         N_ds, self.beta, idx, y = host.observation_bookkeeping(self.X_obs, self.X_obs_discret)
@@ -124,9 +141,18 @@ class MAGI_v2:
         self.y_tau_ds_observed = y
 
         self.X_interp_obs = host.linear_interpolate(self.X_obs_discret[:, self.observed_indicators])
-        hp = dict(host.hparams_initial(self.X_interp_obs))
         if hparams is not None:
+            hp = dict(host.hparams_initial(self.X_interp_obs))
             hp.update({k: np.asarray(v, dtype=np.float64) for k, v in hparams.items()})
+        elif hparam_iters > 0 and hparam_fit_on == "observed":
+            X_rows = host.linear_interpolate(self.X_obs[:, self.observed_indicators])
+            hp = self._fit_kernel_hparams(np.asarray(self.ts_obs, dtype=np.float64), X_rows, verbose=verbose, num_iters=hparam_iters)
+        elif hparam_iters > 0:
+            if hparam_fit_on != "grid":
+                raise ValueError("hparam_fit_on must be 'grid' (reference) or 'observed'")
+            hp = self._fit_kernel_hparams(self.I, self.X_interp_obs, verbose=verbose, num_iters=hparam_iters)
+        else:
+            hp = dict(host.hparams_initial(self.X_interp_obs))
         self.phi1s[self.observed_indicators] = hp["phi1s"]
         self.phi2s[self.observed_indicators] = hp["phi2s"]
         self.sigma_sqs_init[self.observed_indicators] = hp["sigma_sqs"]

@@ -367,6 +367,71 @@ __global__ void k_symmetrize(double* A, int N) {             // A = (A + A^T)/2,
     if (i < N && j < N && j <= i) A[(size_t)i * N + j] = 0.5 * (A[(size_t)i * N + j] + t[threadIdx.x][threadIdx.y]);
 }
 
+
+// =============================================================================================
+// GP hyper-parameter fit (reference: MAGI_v2._fit_kernel_hparams, magi_v2.py:538-691)
+// device pieces: S = Kappa + (sigma^2 + jitter) I, log det from the Cholesky factor, alpha = S^-1 r,
+// and the trace terms of d loglik / d(phi1, phi2, sigma^2) = 1/2 tr((alpha alpha^T - S^-1) dS/d.)
+// =============================================================================================
+__global__ void k_fit_shift(const double* __restrict__ Kap, double* __restrict__ S, int N, double shift) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)N * N) return;
+    const int i = (int)(e / N), j = (int)(e - (size_t)i * N);
+    S[e] = Kap[e] + (i == j ? shift : 0.0);
+}
+
+// out[0] = sum_i log L_ii (one block)
+__global__ __launch_bounds__(256) void k_fit_logdiag(const double* __restrict__ L, int N, double* out) {
+    __shared__ double sh[2 * 16];
+    double v[1] = {0.0};
+    for (int i = threadIdx.x; i < N; i += 256) v[0] += log(L[(size_t)i * N + i]);
+    block_sum<1>(v, sh);
+    if (threadIdx.x == 0) out[0] = v[0];
+}
+
+// alpha = Sinv r ; one wave per row
+__global__ __launch_bounds__(256) void k_fit_gemv(const double* __restrict__ A, const double* __restrict__ r, double* __restrict__ y, int N) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    double s = 0.0;
+    for (int j = lane; j < N; j += 64) s = fma(A[(size_t)row * N + j], r[j], s);
+    s = wave_sum(s);
+    if (lane == 0) y[row] = s;
+}
+
+// per-block partials of: [0] sum W_ij Kap_ij  [1] sum W_ij (-pK_ij (t_i - t_j))  [2] tr Sinv  [3] r.alpha  [4] alpha.alpha
+// with W = alpha alpha^T - Sinv; grid (ceil(N/64), N/ROWS) ; each block handles 4 rows x 64-wide column strips looped
+__global__ __launch_bounds__(256) void k_fit_terms(const double* __restrict__ Kap, const double* __restrict__ pK, const double* __restrict__ Sinv,
+                                                   const double* __restrict__ alpha, const double* __restrict__ r, const double* __restrict__ t,
+                                                   int N, double* __restrict__ part /* [gridDim.x][5] */) {
+    __shared__ double sh[6 * 16];
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (row < N) {
+        const double ai = alpha[row], ti = t[row];
+        for (int j = lane; j < N; j += 64) {
+            const size_t e = (size_t)row * N + j;
+            const double w = ai * alpha[j] - Sinv[e];
+            v[0] = fma(w, Kap[e], v[0]);
+            v[1] = fma(w, -pK[e] * (ti - t[j]), v[1]);
+            if (j == row) v[2] += Sinv[e];
+        }
+        if (lane == 0) { v[3] = r[row] * ai; v[4] = ai * ai; }
+    }
+    block_sum<5>(v, sh);
+    if (threadIdx.x < 5) part[(size_t)blockIdx.x * 5 + threadIdx.x] = v[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_fit_final(const double* __restrict__ part, int nblk, double* out /* [5] */) {
+    __shared__ double sh[6 * 16];
+    double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblk; b += 256)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] += part[(size_t)b * 5 + k];
+    block_sum<5>(v, sh);
+    if (threadIdx.x < 5) out[threadIdx.x] = v[threadIdx.x];
+}
+
 struct Linalg {
     magi_handle* h;
     hipStream_t s;
@@ -583,6 +648,42 @@ struct DevBuf {
     hipError_t alloc(size_t n) { return hipMalloc(&p, n * sizeof(double)); }
 };
 
+
+// One evaluation of the GP marginal log likelihood of component data x (mean mu) and its gradient with
+// respect to (phi1, phi2, sigma^2):  S = phi1 R(phi2) + (sigma^2 + jitter) I
+//   ll = -1/2 r^T S^-1 r - 1/2 log|S| - N/2 log 2pi ,  d ll/d. = 1/2 tr((a a^T - S^-1) dS/d.) , a = S^-1 r
+struct FitWork {
+    DevBuf I, r, Kap, pK, Kpp, S, Sinv, alpha, part, out;
+    Linalg la;
+    int N = 0, nblk = 0;
+};
+
+int fit_eval(magi_handle* h, FitWork& w, double phi1, double phi2, double sig2, double nu, double jitter, double* ll, double* g3) {
+    const int N = w.N;
+    int rc = launch_matern(h, w.I.p, N, phi1, phi2, nu, w.Kap.p, w.pK.p, w.Kpp.p);
+    if (rc) return rc;
+    const size_t nn = (size_t)N * N;
+    hipLaunchKernelGGL(k_fit_shift, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, w.Kap.p, w.S.p, N, sig2 + jitter);
+    if ((rc = potrf(w.la, w.S.p, "GP marginal covariance"))) return rc;
+    hipLaunchKernelGGL(k_fit_logdiag, dim3(1), dim3(256), 0, h->stream, w.S.p, N, w.out.p + 5);
+    if ((rc = trtri(w.la, w.S.p))) return rc;
+    if ((rc = lauum_tt(w.la, w.S.p, w.Sinv.p))) return rc;
+    hipLaunchKernelGGL(k_fit_gemv, dim3((N + 3) / 4), dim3(256), 0, h->stream, w.Sinv.p, w.r.p, w.alpha.p, N);
+    hipLaunchKernelGGL(k_fit_terms, dim3(w.nblk), dim3(256), 0, h->stream, w.Kap.p, w.pK.p, w.Sinv.p, w.alpha.p, w.r.p, w.I.p, N, w.part.p);
+    hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(256), 0, h->stream, w.part.p, w.nblk, w.out.p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("fit launch: ") + hipGetErrorString(e));
+    double o[6];
+    MAGI_HIP_CHECK(h, hipMemcpyAsync(o, w.out.p, sizeof(o), hipMemcpyDeviceToHost, h->stream));
+    MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    const double logdet = 2.0 * o[5];
+    *ll = -0.5 * o[3] - 0.5 * logdet - 0.5 * N * std::log(2.0 * 3.141592653589793);
+    g3[0] = 0.5 * o[0] / phi1;
+    g3[1] = 0.5 * o[1] / phi2;
+    g3[2] = 0.5 * (o[4] - o[2]);
+    return MAGI_OK;
+}
+
 }  // namespace
 
 int magi_fused_operators(magi_handle* h, int N, int D, double* dCs_inout_H, const double* dM, const double* dKs, double* dE) {
@@ -600,6 +701,77 @@ int magi_fused_operators(magi_handle* h, int N, int D, double* dCs_inout_H, cons
     t.C = dCs_inout_H; t.ldc = N; t.M = N; t.N = N; t.K = N; t.alpha = 1.0; t.beta = 1.0;
     t.batchA = nn; t.batchB = nn; t.batchC = nn;
     return launch_gemm(h, h->stream, t, D, BC_FUSED);
+}
+
+// Adam on the softplus-reparameterised (phi1, phi2, sigma^2) of every component, objective
+// D * sum_d [ GP marginal_d + TruncatedNormal priors_d ]  (the [D, D] broadcast of the reference's
+// log_prob, magi_v2.py:604-608, 649-665, summed by tape.gradient), tf_keras Adam(lr) defaults.
+int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const double* X /* [N][D] */, const double* mu,
+                            const double* mu_phi2, const double* sd_phi2, const double* sig_loc, double nu, int iters, double lr,
+                            double jitter, double* phi1, double* phi2, double* sig2, double* loss_trace) {
+    FitWork w;
+    w.N = N;
+    w.nblk = (N + 3) / 4;
+    const size_t nn = (size_t)N * N;
+    MAGI_HIP_CHECK(h, w.I.alloc(N));
+    MAGI_HIP_CHECK(h, w.r.alloc((size_t)N * D));
+    MAGI_HIP_CHECK(h, w.Kap.alloc(nn));
+    MAGI_HIP_CHECK(h, w.pK.alloc(nn));
+    MAGI_HIP_CHECK(h, w.Kpp.alloc(nn));
+    MAGI_HIP_CHECK(h, w.S.alloc(nn));
+    MAGI_HIP_CHECK(h, w.Sinv.alloc(nn));
+    MAGI_HIP_CHECK(h, w.alpha.alloc(N));
+    MAGI_HIP_CHECK(h, w.part.alloc((size_t)w.nblk * 5));
+    MAGI_HIP_CHECK(h, w.out.alloc(8));
+    MAGI_HIP_CHECK(h, hipMemcpy(w.I.p, I, sizeof(double) * N, hipMemcpyHostToDevice));
+    std::vector<double> r((size_t)N * D);
+    for (int d = 0; d < D; ++d)
+        for (int i = 0; i < N; ++i) r[(size_t)d * N + i] = X[(size_t)i * D + d] - mu[d];
+    MAGI_HIP_CHECK(h, hipMemcpy(w.r.p, r.data(), sizeof(double) * N * D, hipMemcpyHostToDevice));
+    int rc = linalg_init(w.la, h, N);
+    if (rc) { linalg_free(w.la); return rc; }
+
+    auto softplus = [](double x) { return std::log1p(std::exp(x)); };
+    auto softplus_inv = [](double y) { return std::log(std::expm1(y)); };
+    auto sigmoid = [](double x) { return 1.0 / (1.0 + std::exp(-x)); };
+    // raw variables, order [phi1(D), phi2(D), sig2(D)] ; Adam state
+    std::vector<double> raw(3 * D), m(3 * D, 0.0), v(3 * D, 0.0), grad(3 * D);
+    for (int d = 0; d < D; ++d) { raw[d] = softplus_inv(phi1[d]); raw[D + d] = softplus_inv(phi2[d]); raw[2 * D + d] = softplus_inv(sig2[d]); }
+    const double sD = std::sqrt((double)D);
+    const double b1 = 0.9, b2 = 0.999, eps = 1e-7;
+    double* const rbase = w.r.p;
+    for (int t = 1; t <= iters && rc == MAGI_OK; ++t) {
+        double loss = 0.0;
+        for (int d = 0; d < D && rc == MAGI_OK; ++d) {
+            const double p1 = softplus(raw[d]), p2 = softplus(raw[D + d]), s2 = softplus(raw[2 * D + d]);
+            double ll, g3[3];
+            w.r.p = rbase + (size_t)d * N;
+            rc = fit_eval(h, w, p1, p2, s2, nu, jitter, &ll, g3);
+            w.r.p = rbase;
+            if (rc) break;
+            // TruncatedNormal(loc, scale, low = 1e-6) priors: only the quadratic depends on the value (magi_v2.py:611-627)
+            const double sc1 = 1000.0 * sD, sc2 = sd_phi2[d] * sD, sc3 = 1000.0 * sD;
+            const double z1 = (p1 - 1e-4) / sc1, z2 = (p2 - mu_phi2[d]) / sc2, z3 = (s2 - sig_loc[d]) / sc3;
+            const double lp = -0.5 * (z1 * z1 + z2 * z2 + z3 * z3);
+            loss -= D * (ll + lp);
+            grad[d] = -D * (g3[0] - z1 / sc1) * sigmoid(raw[d]);
+            grad[D + d] = -D * (g3[1] - z2 / sc2) * sigmoid(raw[D + d]);
+            grad[2 * D + d] = -D * (g3[2] - z3 / sc3) * sigmoid(raw[2 * D + d]);
+        }
+        if (rc) break;
+        if (loss_trace) loss_trace[t - 1] = loss;
+        const double a = lr * std::sqrt(1.0 - std::pow(b2, t)) / (1.0 - std::pow(b1, t));
+        for (int k = 0; k < 3 * D; ++k) {
+            m[k] = b1 * m[k] + (1.0 - b1) * grad[k];
+            v[k] = b2 * v[k] + (1.0 - b2) * grad[k] * grad[k];
+            raw[k] -= a * m[k] / (std::sqrt(v[k]) + eps);
+        }
+    }
+    w.r.p = rbase;
+    linalg_free(w.la);
+    if (rc) return rc;
+    for (int d = 0; d < D; ++d) { phi1[d] = softplus(raw[d]); phi2[d] = softplus(raw[D + d]); sig2[d] = softplus(raw[2 * D + d]); }
+    return MAGI_OK;
 }
 
 int magi_matern_blocks_device(magi_handle* h, const double* I, int N, double phi1, double phi2, double nu, double* Kappa,

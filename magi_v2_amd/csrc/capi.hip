@@ -540,6 +540,20 @@ int magi_sample(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains, const
     return magi_sampler_get_samples(h, X_samps, sig_pre_samps, th_pre_samps);
 }
 
+int magi_fit_hparams(magi_handle* h, const double* I, int N, int D, const double* X_filled, const double* mu, const double* mu_phi2,
+                     const double* sd_phi2, const double* sigma_sq_loc, double nu, int num_iters, double learning_rate, double jitter,
+                     double* phi1, double* phi2, double* sigma_sq, double* loss_trace) {
+    if (!h) return MAGI_E_BADARG;
+    if (!I || !X_filled || !mu || !mu_phi2 || !sd_phi2 || !sigma_sq_loc || !phi1 || !phi2 || !sigma_sq)
+        return magi_fail(h, MAGI_E_BADARG, "null pointer");
+    if (N < 2 || D < 1 || num_iters < 0 || !(nu > 1.0)) return magi_fail(h, MAGI_E_BADARG, "bad N, D, num_iters or nu");
+    for (int d = 0; d < D; ++d)
+        if (!(phi1[d] > 0.0) || !(phi2[d] > 0.0) || !(sigma_sq[d] > 0.0)) return magi_fail(h, MAGI_E_BADARG, "initial values must be positive");
+    (void)hipSetDevice(h->device);
+    return magi_fit_hparams_device(h, I, N, D, X_filled, mu, mu_phi2, sd_phi2, sigma_sq_loc, nu, num_iters, learning_rate, jitter,
+                                   phi1, phi2, sigma_sq, loss_trace);
+}
+
 int magi_build_profile(magi_handle* h, double* flops, double* ms, int64_t* calls) {
     if (!h || !flops || !ms || !calls) return MAGI_E_BADARG;
     long c[16];

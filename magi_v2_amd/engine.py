@@ -44,6 +44,8 @@ _SYMBOLS = {
     "magi_version": (C.c_char_p, []),
     "magi_build_matrices": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, _dp, _dp, _dp]),
     "magi_matern_blocks": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp]),
+    "magi_fit_hparams": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_double,
+                                   C.c_double, _dp, _dp, _dp, _dp]),
     "magi_set_matrices": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]),
     "magi_set_problem": (C.c_int, [C.c_void_p, _dp, _dp, _lp, _dp, C.c_int64, C.c_double, _dp, C.c_int, C.c_int]),
     "magi_logpost_grad": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp]),
@@ -157,6 +159,22 @@ class MagiEngine:
                                                   *[_ptr(o) for o in outs]))
         self.N, self.D = N, D
         return tuple(outs) if want_host else None
+
+    def fit_hparams(self, I, X_filled, mu, mu_phi2, sd_phi2, sigma_sq_loc, phi1_init, phi2_init, sigma_sq_init, nu=2.01,
+                    num_iters=1000, learning_rate=0.01, jitter=1e-6, want_trace=False):
+        """magi_v2.py:538-691 on the GPU; returns dict(phi1s, phi2s, sigma_sqs[, loss])."""
+        I = _f64(np.asarray(I).reshape(-1))
+        X = _f64(X_filled)
+        N, D = X.shape
+        phi1, phi2, sig = _f64(phi1_init, (D,)).copy(), _f64(phi2_init, (D,)).copy(), _f64(sigma_sq_init, (D,)).copy()
+        trace = np.zeros(max(num_iters, 1)) if want_trace else None
+        self._check(self._lib.magi_fit_hparams(self._h, _ptr(I), N, D, _ptr(X), _ptr(_f64(mu, (D,))), _ptr(_f64(mu_phi2, (D,))),
+                                               _ptr(_f64(sd_phi2, (D,))), _ptr(_f64(sigma_sq_loc, (D,))), float(nu), int(num_iters),
+                                               float(learning_rate), float(jitter), _ptr(phi1), _ptr(phi2), _ptr(sig), _ptr(trace)))
+        out = {"phi1s": phi1, "phi2s": phi2, "sigma_sqs": sig}
+        if want_trace:
+            out["loss"] = trace[:num_iters]
+        return out
 
     def matern_blocks(self, I, phi1, phi2, nu=2.01):
         I = _f64(np.asarray(I).reshape(-1))

@@ -118,6 +118,66 @@ def hparams_initial(X_filled: np.ndarray) -> Dict[str, np.ndarray]:
 
 
 # --------------------------------------------------------------------------------------
+# GP hyper-parameter fit (magi_v2.py:538-691) -- PARITY UNPINNED (TFP GaussianProcess /
+# GeneralizedMatern / TruncatedNormal / tf_keras Adam are not in the reference tree).  Restated:
+# objective D * sum_d [GP marginal_d + priors_d] (the [D, D] broadcast of log_prob summed by
+# tape.gradient, :604-608, 649-665), GP covariance phi1 R_nu(phi2) + (sigma^2 + 1e-6) I with the
+# constant mean of :559, softplus-reparameterised variables (:631-642), Adam(lr=.01) x 1000 (:654-678).
+# --------------------------------------------------------------------------------------
+
+
+def gp_marginal_and_grad(I, x, mu, phi1, phi2, sig2, nu=2.01, jitter=1e-6):
+    """log N(x; mu, S) and d/d(phi1, phi2, sig2), S = Kappa(phi1, phi2) + (sig2 + jitter) I."""
+    I = np.asarray(I, dtype=np.float64).reshape(-1)
+    N = I.shape[0]
+    Kap, pK, _ = matern_blocks(I.reshape(-1, 1), phi1, phi2, nu)
+    S = Kap + (sig2 + jitter) * np.eye(N)
+    L = np.linalg.cholesky(S)
+    r = x - mu
+    Sinv = np.linalg.inv(S)
+    a = Sinv @ r
+    ll = -0.5 * r @ a - np.sum(np.log(np.diag(L))) - 0.5 * N * np.log(2.0 * np.pi)
+    W = np.outer(a, a) - Sinv
+    dK2 = -pK * (I[:, None] - I[None, :]) / phi2
+    return ll, np.array([0.5 * np.sum(W * Kap) / phi1, 0.5 * np.sum(W * dK2), 0.5 * np.trace(W)])
+
+
+def fit_kernel_hparams(I, X_filled, num_iters=1000, lr=0.01, nu=2.01, jitter=1e-6, init=None, trace=None):
+    """``_fit_kernel_hparams`` (magi_v2.py:538-691) restated in numpy."""
+    N, D = X_filled.shape
+    mu = X_filled.mean(axis=0)
+    pri = [fourier_phi2_prior(X_filled[:, d]) for d in range(D)]
+    mu_phi2, sd_phi2 = np.array([p[0] for p in pri]), np.array([p[1] for p in pri])
+    hp = hparams_initial(X_filled) if init is None else init
+    sig_loc = (X_filled.std(axis=0) * 0.1) ** 2
+    sp_inv = lambda y: np.log(np.expm1(y))
+    sp = lambda x: np.log1p(np.exp(x))
+    sg = lambda x: 1.0 / (1.0 + np.exp(-x))
+    raw = np.concatenate([sp_inv(hp["phi1s"]), sp_inv(hp["phi2s"]), sp_inv(hp["sigma_sqs"])])
+    m, v = np.zeros_like(raw), np.zeros_like(raw)
+    sD = np.sqrt(D)
+    for t in range(1, num_iters + 1):
+        grad = np.zeros_like(raw)
+        loss = 0.0
+        for d in range(D):
+            p1, p2, s2 = sp(raw[d]), sp(raw[D + d]), sp(raw[2 * D + d])
+            ll, g3 = gp_marginal_and_grad(I, X_filled[:, d], mu[d], p1, p2, s2, nu, jitter)
+            sc = np.array([1000.0 * sD, sd_phi2[d] * sD, 1000.0 * sD])
+            z = (np.array([p1, p2, s2]) - np.array([1e-4, mu_phi2[d], sig_loc[d]])) / sc
+            loss -= D * (ll - 0.5 * np.sum(z * z))
+            gtot = g3 - z / sc
+            for k in range(3):
+                grad[k * D + d] = -D * gtot[k] * sg(raw[k * D + d])
+        if trace is not None:
+            trace.append(loss)
+        a = lr * np.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
+        m = 0.9 * m + 0.1 * grad
+        v = 0.999 * v + 0.001 * grad * grad
+        raw = raw - a * m / (np.sqrt(v) + 1e-7)
+    return {"phi1s": sp(raw[:D]), "phi2s": sp(raw[D:2 * D]), "sigma_sqs": sp(raw[2 * D:])}
+
+
+# --------------------------------------------------------------------------------------
 # Kernel matrices (magi_v2.py:774-823, 126-128, 271-274)
 # --------------------------------------------------------------------------------------
 

@@ -161,3 +161,22 @@ def test_oracle_nuts_samples_a_correlated_gaussian():
     assert np.abs(draws.mean(axis=0) - mean).max() < 0.25
     assert np.abs(np.cov(draws.T) - cov).max() < 0.35 * np.abs(cov).max()
     assert 0.55 < da.step_size < 3.0
+
+
+def test_oracle_gp_marginal_gradient_matches_finite_differences(golden_dir):
+    """The f1 restatement (magi_v2.py:538-691, unpinned against TFP) is at least internally consistent:
+    analytic d loglik / d(phi1, phi2, sigma^2) = central differences."""
+    g = _load(golden_dir, "g3_pipeline.npz")
+    I, X = g["seir3_I"][:41, 0], g["seir3_X_interp"][:41]
+    x, mu = X[:, 1], X[:, 1].mean()
+    p = np.array([0.02, 0.3, 1e-4])
+    ll, gr = orc.gp_marginal_and_grad(I, x, mu, *p)
+    for k in range(3):
+        h = 1e-6 * p[k]
+        pp, pm = p.copy(), p.copy()
+        pp[k] += h
+        pm[k] -= h
+        fd = (orc.gp_marginal_and_grad(I, x, mu, *pp)[0] - orc.gp_marginal_and_grad(I, x, mu, *pm)[0]) / (2 * h)
+        assert abs(fd - gr[k]) <= 1e-5 * abs(gr[k]) + 1e-6, (k, fd, gr[k])
+    out = orc.fit_kernel_hparams(I, X, num_iters=3)
+    assert all(np.all(v > 0) for v in out.values())
