@@ -182,14 +182,16 @@ int magi_sample(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains,
 /* ---- instrumentation (bench.py roofline leg) ----------------------------------------------- */
 
 /* Launch one gradient evaluation (the 3 mat-vec phases + reduce) `reps` times on the handle's
- * stream, bracketed by HIP events on that stream; phase_ms[6] receives the average device
- * time per launch of phase 1, 2, 3, the reduce kernel, the sampler's single-phase mat-vec kernel
- * and its reduce, measured in separate event-bracketed loops.  Uses the states currently on the
+ * stream, bracketed by HIP events on that stream; phase_ms[8] receives the average device
+ * time per launch of phase 1, 2, 3, the reduce kernel, the sampler's streaming kernel (single-phase
+ * block mat-vecs, k_stream), its reduce (k_leap_finalize) and its point kernel (k_point; [7] is
+ * unused), measured in separate event-bracketed loops.  Uses the states currently on the
  * device (n_chains as last set). */
 int magi_time_gradient(magi_handle* h, int n_chains, int reps, double* total_ms_per_eval, double* phase_ms);
 
-/* Bytes each of those six kernels must move per launch for the current matrices and n_chains
- * (DESIGN.md section 4.1). */
+/* phase_bytes[8]: bytes each of those seven kernels must move per launch for the current matrices
+ * and n_chains; [7] = the algorithmic bytes of one gradient evaluation as
+ * SURVEY 8d counts them (3 D N W 8 + C 10 N D 8). */
 int magi_gradient_bytes(magi_handle* h, int n_chains, double* phase_bytes);
 
 /* Diagnostics: per-class device time of the last magi_build_matrices when the environment variable

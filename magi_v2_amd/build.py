@@ -38,7 +38,10 @@ def build_lib(force=False, verbose=True):
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
                 and all(os.path.getmtime(obj) > os.path.getmtime(hh) for hh in hdrs)):
             continue
-        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function"] + \
+        # -ffp-contract=on: fused multiply-adds are formed per source expression (front end), not by the optimiser, so
+        # every instantiation of a kernel (1, 2, 4 chains per matrix pass) rounds a chain's arithmetic identically
+        contract = [] if os.path.basename(src) == "build.hip" else ["-ffp-contract=on"]     # (the matrix build keeps the default)
+        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function"] + contract + \
             os.environ.get("MAGI_EXTRA_CFLAGS", "").split() + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -22,16 +22,16 @@ void free_dev(void* p) { if (p) (void)hipFree(p); }
 
 void free_matrices(magi_handle* h) {
     free_dev(h->dCsym); free_dev(h->dM); free_dev(h->dMt); free_dev(h->dKsym); free_dev(h->dYobs);
-    free_dev(h->dFH); free_dev(h->dFE); free_dev(h->dFEt); free_dev(h->dFK);
+    free_dev(h->dTiles); free_dev(h->dTasks);
     h->dCsym = h->dM = h->dMt = h->dKsym = h->dYobs = nullptr;
-    h->dFH = h->dFE = h->dFEt = h->dFK = nullptr;
-    h->fused_elems = 0;
+    h->dTiles = nullptr; h->dTasks = nullptr;
+    h->tiles_cap = h->tasks_cap = 0;
     h->have_matrices = h->have_problem = false;
 }
 
 void free_chains(magi_handle* h) {
     DevChains& c = h->ch;
-    free_dev(c.vec); free_dev(c.ctl); free_dev(c.par); free_dev(c.plan); free_dev(c.part); free_dev(c.gctl); free_dev(c.samples);
+    free_dev(c.vec); free_dev(c.ctl); free_dev(c.par); free_dev(c.plan); free_dev(c.part); free_dev(c.tpart); free_dev(c.ticket); free_dev(c.gctl); free_dev(c.samples);
     free_dev(c.d_step_size); free_dev(c.d_lar); free_dev(c.d_target); free_dev(c.d_energy); free_dev(c.d_beta);
     free_dev(c.d_leapfrogs); free_dev(c.d_depth); free_dev(c.d_flags);
     free_dev(h->d_chain_ids); free_dev(h->d_fin);
@@ -81,7 +81,7 @@ int build_graph(magi_handle* h) {
     MAGI_HIP_CHECK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     int rc = MAGI_OK;
     for (int s = 0; s < kGraphSlots && rc == MAGI_OK; ++s) {
-        rc = magi_launch_leap(h, h->n_chains, h->stream);
+        rc = magi_launch_stream(h, h->n_chains, h->stream);
         if (rc == MAGI_OK) rc = magi_launch_tail(h, h->n_chains, h->stream);
     }
     hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
@@ -112,6 +112,11 @@ int magi_ensure_chains(magi_handle* h, int n) {
         h->ch.n_wg = magi_leap_wgs(h->pb);
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.part, sizeof(double) * PART_K * h->ch.n_wg * n));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.part, 0, sizeof(double) * PART_K * h->ch.n_wg * n));
+        MAGI_HIP_CHECK(h, hipMalloc(&h->ch.ticket, sizeof(int) * n));
+        MAGI_HIP_CHECK(h, hipMemset(h->ch.ticket, 0, sizeof(int) * n));
+        const size_t tpn = (size_t)n * 4 * h->pb.D * h->pb.nb * h->pb.Np;
+        MAGI_HIP_CHECK(h, hipMalloc(&h->ch.tpart, sizeof(double) * tpn));
+        MAGI_HIP_CHECK(h, hipMemset(h->ch.tpart, 0, sizeof(double) * tpn));     // slots outside the block band stay zero
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.gctl, sizeof(GlobalCtl)));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.gctl, 0, sizeof(GlobalCtl)));
         MAGI_HIP_CHECK(h, hipMalloc(&h->d_chain_ids, sizeof(long long) * n));
@@ -379,9 +384,10 @@ int magi_sampler_init(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains,
     for (int i = 0; i < n_chains; ++i) ids[i] = chain_ids ? (long long)chain_ids[i] : (long long)i;
     MAGI_HIP_CHECK(h, hipMemcpy(h->d_chain_ids, ids.data(), sizeof(long long) * n_chains, hipMemcpyHostToDevice));
     if ((rc = magi_launch_init_chains(h, h->d_chain_ids, h->stream))) return rc;
+    MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.ticket, 0, sizeof(int) * n_chains, h->stream));
     // bootstrap_results: one gradient at the initial state (the tail stores it as the proposal)
     if ((rc = magi_launch_prepare(h, n_chains, h->stream))) return rc;
-    if ((rc = magi_launch_leap(h, n_chains, h->stream))) return rc;
+    if ((rc = magi_launch_stream(h, n_chains, h->stream))) return rc;
     if ((rc = magi_launch_tail(h, n_chains, h->stream))) return rc;
     MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     h->epoch = 0;
@@ -423,6 +429,8 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
     g.stop_k = std::min(h->cfg.total, kmin + n_steps);
     g.epoch = ++h->epoch;
     MAGI_HIP_CHECK(h, hipMemcpyAsync(h->ch.gctl, &g, sizeof(GlobalCtl), hipMemcpyHostToDevice, h->stream));
+    // workgroups that saw all_done flip in the middle of the previous run's last launch left partial ticket counts
+    MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.ticket, 0, sizeof(int) * h->n_chains, h->stream));
     MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // &g is pageable stack memory
     MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t0, h->stream));
 
@@ -438,7 +446,7 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
                 MAGI_HIP_CHECK(h, hipGraphLaunch(h->graph_exec, h->stream));
             } else {
                 for (int sl = 0; sl < kGraphSlots; ++sl) {
-                    if ((rc = magi_launch_leap(h, h->n_chains, h->stream))) return rc;
+                    if ((rc = magi_launch_stream(h, h->n_chains, h->stream))) return rc;
                     if ((rc = magi_launch_tail(h, h->n_chains, h->stream))) return rc;
                 }
             }
@@ -580,9 +588,11 @@ int magi_gradient_bytes(magi_handle* h, int n_chains, double* phase_bytes) {
     phase_bytes[1] = 1.0 * mat + 2.0 * vec;   // Ksym    ; read r, write Kr
     phase_bytes[2] = 1.0 * mat + 5.0 * vec;   // Mt      ; read Kr, X, Cx, yobs, write gX
     phase_bytes[3] = 5.0 * vec;               // reduce  ; read X, Cx, r, Kr, yobs
-    const double Wf = pb.bandf < 0 ? (double)pb.N : (double)(2 * pb.bandf + 1);
-    phase_bytes[4] = 4.0 * (double)pb.D * pb.N * Wf * 8.0 + 8.0 * vec;   // leap: FH, FE, FEt, FK ; X, yobs, p, rho ; g, p_leaf, p', x'
+    const double nslot = (double)std::min(pb.nb, 2 * pb.wb + 1);
+    phase_bytes[4] = (double)pb.n_tasks * MAGI_TB * MAGI_TB * 8.0 + 2.0 * (double)n_chains * pb.n_tasks * MAGI_TB * 8.0;   // k_stream: packed blocks of FH, FK (lower block triangle), FE; writes 2 TB partials per block and chain
     phase_bytes[5] = (double)n_chains * magi_leap_wgs(pb) * PART_K * 8.0; // tail: the workgroup partials
+    phase_bytes[6] = 4.0 * vec * nslot + 10.0 * vec;                       // k_point: block partials of the four products; X, yobs, p, rho, g, p_leaf, p', x'
+    phase_bytes[7] = 3.0 * (double)pb.D * pb.N * W * 8.0 + 10.0 * vec;    // SURVEY 8d algorithmic bytes of one gradient evaluation
     return MAGI_OK;
 }
 
@@ -613,13 +623,14 @@ int magi_time_gradient(magi_handle* h, int n_chains, int reps, double* total_ms_
     MAGI_HIP_CHECK(h, hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
     if (total_ms_per_eval) *total_ms_per_eval = ms / reps;
     if (phase_ms) {
-        for (int ph = 1; ph <= 6; ++ph) {
+        for (int ph = 1; ph <= 7; ++ph) {
             MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t0, h->stream));
             for (int i = 0; i < reps; ++i) {
                 if (ph <= 3) rc = magi_launch_phase(h, ph, n_chains, h->stream);
                 else if (ph == 4) rc = magi_launch_finalize(h, n_chains, h->d_fin, h->stream);
-                else if (ph == 5) rc = magi_launch_leap(h, n_chains, h->stream);
-                else rc = magi_launch_leap_finalize(h, n_chains, h->d_fin, h->stream);
+                else if (ph == 5) rc = magi_launch_stream(h, n_chains, h->stream);
+                else if (ph == 6) rc = magi_launch_leap_finalize(h, n_chains, h->d_fin, h->stream);
+                else rc = magi_launch_point(h, n_chains, h->stream);
                 if (rc) return rc;
             }
             MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t1, h->stream));

@@ -14,128 +14,11 @@
 // (reference arithmetic: magi_v2.py:308-348 and the leapfrog of TFP's NoUTurnSampler)
 #include "magi_internal.h"
 #include "leap_reduce.h"
+#include "leap_point.h"
 
 namespace {
 
-constexpr int LEAP_RI = 2;
-
-template <int DRIFT>
-struct GridPoint {     // finishes component d of grid index i of one chain (one lane)
-    using DR = DriftT<DRIFT>;
-    static constexpr int D = DR::D, P = DR::P;
-
-    static __device__ __forceinline__ void finish(const DevProblem& pb, const DevChains& ch, int cc, int i, int d, const double* res /* [D][4] */,
-                                                  double* pk /* [PART_K] */) {
-        const LeafPlan lp = ch.plan[cc];
-#pragma unroll
-        for (int k = 0; k < PART_K; ++k) pk[k] = 0.0;
-        if (!lp.active) return;
-        const int N = pb.N, dimp = pb.dimp;
-        double* vb = ch.vec + vec_off(pb, cc, 0);
-        const double* par = ch.par + (size_t)cc * PAR_COUNT;
-        const double* q = vb + (size_t)(V_Q + lp.cur) * dimp;
-        const int e = d * N + i;
-        // this lane's own operands first (independent of the drift algebra)
-        const double y = pb.yobs[e];
-        const double* ph = vb + (size_t)(V_P + lp.cur) * dimp;
-        double* rho = vb + (size_t)V_RHOSUB * dimp;
-        double* ckp = vb + (size_t)V_CKP0 * dimp;
-        double* ckr = vb + (size_t)V_CKRHO0 * dimp;
-        double phe = 0.0, rhoe = 0.0, cpk[4] = {0.0, 0.0, 0.0, 0.0}, crk[4] = {0.0, 0.0, 0.0, 0.0};
-        if (lp.leaf) {
-            phe = ph[e];
-            rhoe = rho[e];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < lp.nchk) { cpk[k] = ckp[(size_t)lp.chk_slot[k] * dimp + e]; crk[k] = ckr[(size_t)lp.chk_slot[k] * dimp + e]; }
-        }
-        double th[P], x[D], f[D], g2[D], jt[D], tp[P];
-#pragma unroll
-        for (int k = 0; k < P; ++k) { th[k] = par[PAR_TH + k]; tp[k] = 0.0; }
-#pragma unroll
-        for (int dd = 0; dd < D; ++dd) x[dd] = q[dd * N + i];
-        DR::f(x, th, f);
-#pragma unroll
-        for (int dd = 0; dd < D; ++dd) g2[dd] = 2.0 * (res[dd * 4 + 3] - res[dd * 4 + 1]);
-        DR::jt(x, th, g2, jt, tp);
-        // select this lane's component
-        double xd = x[0], fd = f[0], jtd = jt[0], mud = pb.mu[0];
-#pragma unroll
-        for (int dd = 1; dd < D; ++dd) if (d == dd) { xd = x[dd]; fd = f[dd]; jtd = jt[dd]; mud = pb.mu[dd]; }
-        const double hx = res[d * 4 + 0], ex = res[d * 4 + 1], etf = res[d * 4 + 2], kf = res[d * 4 + 3];
-        pk[PK_T12] = (xd - mud) * hx + fd * (kf - 2.0 * ex);
-        if (d == 0) {
-#pragma unroll
-            for (int k = 0; k < P; ++k) pk[PK_TP + k] = tp[k];
-        }
-        double d4 = 0.0;
-        if (!isnan(y)) {
-            const double df = xd - y;
-            pk[PK_SS + d] = df * df;
-            d4 = 2.0 * df / par[PAR_SIG2 + d];
-        }
-        const double gx = -0.5 * (pb.beta_inv * (2.0 * hx - 2.0 * etf + jtd) + d4);
-        (vb + (size_t)V_G * dimp)[e] = gx;
-        if (lp.leaf) {
-            const double pn = phe + lp.hs * gx;
-            (vb + (size_t)V_PLEAF * dimp)[e] = pn;
-            const double rs = rhoe + pn;
-            rho[e] = rs;
-            pk[PK_PP] = pn * pn;
-            if (lp.even) { ckp[(size_t)lp.ck_slot * dimp + e] = pn; ckr[(size_t)lp.ck_slot * dimp + e] = rs; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < lp.nchk) { const double df = rs - crk[k]; pk[PK_DOT + 2 * k] = df * cpk[k]; pk[PK_DOT + 2 * k + 1] = df * pn; }
-            const double pnext = pn + lp.hs * gx;
-            (vb + (size_t)(V_P + (lp.cur ^ 1)) * dimp)[e] = pnext;
-            (vb + (size_t)(V_Q + (lp.cur ^ 1)) * dimp)[e] = xd + lp.eps * pnext;
-        }
-    }
-};
-
-// common tail of the dense and banded kernels: row sums are in (ah, ae, at, ak)[NC] of every lane
-template <int NC, int DRIFT>
-__device__ __forceinline__ void leap_epilogue(const DevProblem& pb, const DevChains& ch, int c0, int ri, int d, int lane,
-                                              const double (&ah)[NC], const double (&ae)[NC], const double (&at)[NC], const double (&ak)[NC],
-                                              double* res /* [RI][NC][D][4] */, double* redk /* [RI][NC][D][PART_K] */) {
-    constexpr int D = DriftT<DRIFT>::D;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const double s0 = wave_sum(ah[c]), s1 = wave_sum(ae[c]), s2 = wave_sum(at[c]), s3 = wave_sum(ak[c]);
-        if (lane == 0) {
-            double* r = res + (((size_t)ri * NC + c) * D + d) * 4;
-            r[0] = s0; r[1] = s1; r[2] = s2; r[3] = s3;
-        }
-    }
-    __syncthreads();
-    const int t = threadIdx.x;
-    if (t < LEAP_RI * NC * D) {
-        const int dd = t % D, rc = t / D;
-        const int rr = rc / NC, c = rc - rr * NC;
-        const int i = blockIdx.x * LEAP_RI + rr, cc = c0 + c;
-        double* pk = redk + (size_t)t * PART_K;
-        if (i < pb.N && cc < ch.n_chains) {
-            GridPoint<DRIFT>::finish(pb, ch, cc, i, dd, res + ((size_t)rr * NC + c) * D * 4, pk);
-        } else {
-#pragma unroll
-            for (int k = 0; k < PART_K; ++k) pk[k] = 0.0;
-        }
-    }
-    __syncthreads();
-    if (t < NC * PART_K) {
-        const int c = t / PART_K, k = t - c * PART_K;
-        if (c0 + c < ch.n_chains) {
-            double s = 0.0;
-#pragma unroll
-            for (int rr = 0; rr < LEAP_RI; ++rr)
-#pragma unroll
-                for (int dd = 0; dd < D; ++dd) s += redk[(((size_t)rr * NC + c) * D + dd) * PART_K + k];
-            ch.part[((size_t)(c0 + c) * PART_K + k) * ch.n_wg + blockIdx.x] = s;
-        }
-    }
-}
-
-// extra block (blockIdx.x == n_wg): the data-independent uniform draws of the leaf in flight, so the
+// extra block of the streaming kernel: the data-independent uniform draws of the leaf in flight, so the
 // tail starts with them in memory instead of evaluating two fp64 log1p on its critical path
 template <int NC>
 __device__ __forceinline__ void leap_service(const DevChains& ch, int c0) {
@@ -150,155 +33,176 @@ __device__ __forceinline__ void leap_service(const DevChains& ch, int c0) {
     }
 }
 
-// ---- dense operators: grid (ceil(N / RI), ceil(n_chains / NC)), block 64 * D * RI -------------------
-// FVEC: the drift of every chain's state has been stored by k_drift (V_F) -- used when several chains share
-// the matrix stream, where re-evaluating the drift for every matrix row (N-fold redundant) would dominate
-template <int NC, int DRIFT, bool FVEC>
-__global__ __launch_bounds__(64 * DriftT<DRIFT>::D * LEAP_RI) void k_leap_dense(DevProblem pb, DevChains ch) {
-    using DR = DriftT<DRIFT>;
-    constexpr int D = DR::D, P = DR::P;
-    if (ch.gctl->all_done) return;
-    if (blockIdx.x == ch.n_wg) { leap_service<NC>(ch, blockIdx.y * NC); return; }
-    __shared__ double res[LEAP_RI * NC * D * 4];
-    __shared__ double redk[LEAP_RI * NC * D * PART_K];
-    const int N = pb.N, ld = pb.ldf;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ri = wave / D, d = wave - ri * D;
-    const int i = blockIdx.x * LEAP_RI + ri, ii = min(i, N - 1);
-    const int c0 = blockIdx.y * NC;
-    const size_t ro = ((size_t)d * N + ii) * ld;
-    const double2* ph = reinterpret_cast<const double2*>(pb.FH + ro);
-    const double2* pe = reinterpret_cast<const double2*>(pb.FE + ro);
-    const double2* pt = reinterpret_cast<const double2*>(pb.FEt + ro);
-    const double2* pk = reinterpret_cast<const double2*>(pb.FK + ro);
-    const double mud = pb.mu[d];
+__device__ __forceinline__ double sel4(const double (&a)[MAGI_MAX_D], int d) {
+    return d == 0 ? a[0] : d == 1 ? a[1] : d == 2 ? a[2] : a[3];
+}
 
-    const double* qc[NC];
-    const double* fc[NC];
-    double th[NC][P];
+// Transposed butterfly: v[0..8) per lane -> every lane returns the 64-lane sum of v[lane >> 3].
+// Halving steps hand half of the values to the partner (v_permlane32/16_swap move both halves in one
+// instruction pair), so 8 row sums cost 7 exchanges + 3 plain steps instead of 8 x 6.
+__device__ __forceinline__ double swap_add32(double a, double b) {
+    unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double swap_add16(double a, double b) {
+    unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double tsum8(const double (&v)[8], int lane) {
+    // lanes 32..63 keep rows 4..7, lanes 0..31 rows 0..3
+    const double s0 = swap_add32(v[0], v[4]), s1 = swap_add32(v[1], v[5]), s2 = swap_add32(v[2], v[6]), s3 = swap_add32(v[3], v[7]);
+    // odd rows of 16 lanes keep the upper two of those
+    const double u0 = swap_add16(s0, s2), u1 = swap_add16(s1, s3);
+    // lanes with bit 3 set keep u1 (partner: row_mirror, which flips bit 3)
+    const bool hi8 = (lane & 8) != 0;
+    const double keep = hi8 ? u1 : u0, send = hi8 ? u0 : u1;
+    double w = keep + dpp_f64<0x140>(send);
+    w += dpp_f64<0x141>(w);   // row_half_mirror (stays inside the 8-lane group)
+    w += dpp_f64<0x4E>(w);
+    w += dpp_f64<0xB1>(w);
+    return w;
+}
+
+constexpr int ST_WAVES = 4;                    // waves per block task
+constexpr int ST_RW = MAGI_TB / ST_WAVES;      // rows of the block per wave
+
+// ---- streaming kernel: one TB x TB block of FH / FK / FE per workgroup ----------------------------------
+// grid (n_tasks + 1, ceil(n_chains / NC)), block 64 * ST_WAVES.  Wave w streams rows [w*RW, (w+1)*RW) of the block with
+// 16-B coalesced loads (lane = two columns) and forms, for up to NC chains sharing the bytes,
+//   row-type products   (A v_col)[r]   -> transposed butterflies, one partial per block row
+//   column-type products (A^T v_row)[c] -> per-lane accumulators, combined over the waves in LDS
+// where v is xc = X_d - mu_d or f_d = drift_d(X, theta) as the operator requires (evaluated on the fly from the
+// state vector).  The partials go to tpart[chain][vec][d][other block][i]; k_point adds them in fixed order.
+template <int NC, int DRIFT>
+__global__ __launch_bounds__(64 * ST_WAVES) __attribute__((amdgpu_waves_per_eu(NC == 1 ? 4 : NC == 2 ? 3 : 2))) void k_stream(DevProblem pb, DevChains ch) {
+    using DR = DriftT<DRIFT>;
+    constexpr int D = DR::D, P = DR::P, TB = MAGI_TB;
+    if (ch.gctl->all_done) return;
+    const int c0 = blockIdx.y * NC;
+    if ((int)blockIdx.x == pb.n_tasks) { leap_service<NC>(ch, c0); return; }
+#ifdef MAGI_TAIL_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) ch.par[(size_t)c0 * PAR_COUNT + 40 + 7] = (double)__builtin_amdgcn_s_memrealtime();
+    if ((int)blockIdx.x == pb.n_tasks - 1 && threadIdx.x == 0) ch.par[(size_t)c0 * PAR_COUNT + 40 + 10] = (double)__builtin_amdgcn_s_memrealtime();
+#endif
+    __shared__ double vcol[NC][TB], vrow[NC][TB], rowout[NC][TB], colacc[ST_WAVES][NC][TB];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int4 task = reinterpret_cast<const int4*>(pb.tasks)[blockIdx.x];
+    const int d = task.x, kind = task.y, bi = task.z, bj = task.w;
+    const int N = pb.N;
+
+    // operands of this thread's vector entry (issued before the tile stream so that their wait does not
+    // cover the 32 row loads behind them)
+    const bool isrow = t >= TB;
+    const int loc = isrow ? t - TB : t;
+    const int gi = (isrow ? bi : bj) * TB + loc;
+    const bool wantf = isrow ? (kind != TK_FH) : (kind == TK_FK);
+    const double mud = sel4(pb.mu, d);
+    double xin[NC][D], thv[NC][P];
+    bool act[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int cc = min(c0 + c, ch.n_chains - 1);
-        qc[c] = ch.vec + vec_off(pb, cc, V_Q + ch.plan[cc].cur);
-        fc[c] = ch.vec + vec_off(pb, cc, V_F) + (size_t)d * N;
+        const LeafPlan* lp = ch.plan + cc;
+        act[c] = (c0 + c < ch.n_chains) && lp->active != 0;
+        const double* q = ch.vec + vec_off(pb, cc, V_Q + lp->cur);
 #pragma unroll
-        for (int k = 0; k < P; ++k) th[c][k] = FVEC ? 0.0 : ch.par[(size_t)cc * PAR_COUNT + PAR_TH + k];
+        for (int dd = 0; dd < D; ++dd) xin[c][dd] = q[dd * N + min(gi, N - 1)];
+#pragma unroll
+        for (int k = 0; k < P; ++k) thv[c][k] = ch.par[(size_t)cc * PAR_COUNT + PAR_TH + k];
     }
-    double ah[NC], ae[NC], at[NC], ak[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) { ah[c] = 0.0; ae[c] = 0.0; at[c] = 0.0; ak[c] = 0.0; }
 
-    const int n2 = ld >> 1;
-#pragma unroll 2
-    for (int jj = lane; jj < n2; jj += 64) {
-        const double2 h = ph[jj], e = pe[jj], t = pt[jj], k = pk[jj];
-        const int j0 = 2 * jj, j1 = min(2 * jj + 1, N - 1);     // ld is N rounded up to even: the pad column is zero
+    // the wave's rows in chunks of 8, two chunks in flight (a0 / a1): 16 KB per wave on the wire while one chunk is in the ALUs
+    const double2* A = reinterpret_cast<const double2*>(pb.tiles + (size_t)blockIdx.x * TB * TB + (size_t)(wave * ST_RW) * TB) + lane;
+    constexpr int NCK = ST_RW / 8;
+    double2 a0[8], a1[8];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (FVEC) {
-                const double xca = qc[c][d * N + j0] - mud, xcb = qc[c][d * N + j1] - mud;
-                const double fa = fc[c][j0], fb = fc[c][j1];
-                ah[c] = fma(h.x, xca, ah[c]); ah[c] = fma(h.y, xcb, ah[c]);
-                ae[c] = fma(e.x, xca, ae[c]); ae[c] = fma(e.y, xcb, ae[c]);
-                at[c] = fma(t.x, fa, at[c]); at[c] = fma(t.y, fb, at[c]);
-                ak[c] = fma(k.x, fa, ak[c]); ak[c] = fma(k.y, fb, ak[c]);
-                continue;
-            }
-            double xa[D], xb[D];
+    for (int r = 0; r < 8; ++r) a0[r] = A[(size_t)r * (TB / 2)];
 #pragma unroll
-            for (int dd = 0; dd < D; ++dd) { xa[dd] = qc[c][dd * N + j0]; xb[dd] = qc[c][dd * N + j1]; }
-            double xda = xa[0], xdb = xb[0];
-#pragma unroll
-            for (int dd = 1; dd < D; ++dd) if (d == dd) { xda = xa[dd]; xdb = xb[dd]; }
-            const double fa = DR::f1(d, xa, th[c]), fb = DR::f1(d, xb, th[c]);
-            const double xca = xda - mud, xcb = xdb - mud;
-            ah[c] = fma(h.x, xca, ah[c]); ah[c] = fma(h.y, xcb, ah[c]);
-            ae[c] = fma(e.x, xca, ae[c]); ae[c] = fma(e.y, xcb, ae[c]);
-            at[c] = fma(t.x, fa, at[c]); at[c] = fma(t.y, fb, at[c]);
-            ak[c] = fma(k.x, fa, ak[c]); ak[c] = fma(k.y, fb, ak[c]);
-        }
-    }
-    leap_epilogue<NC, DRIFT>(pb, ch, c0, ri, d, lane, ah, ae, at, ak, res, redk);
-}
+    for (int r = 0; r < 8; ++r) a1[r] = A[(size_t)(8 + r) * (TB / 2)];
+    __builtin_amdgcn_sched_barrier(0);
 
-// ---- banded operators: rows hold columns [i - bf, i + bf] ---------------------------------------------
-template <int NC, int DRIFT, bool FVEC>
-__global__ __launch_bounds__(64 * DriftT<DRIFT>::D * LEAP_RI) void k_leap_band(DevProblem pb, DevChains ch) {
-    using DR = DriftT<DRIFT>;
-    constexpr int D = DR::D, P = DR::P;
-    if (ch.gctl->all_done) return;
-    if (blockIdx.x == ch.n_wg) { leap_service<NC>(ch, blockIdx.y * NC); return; }
-    __shared__ double res[LEAP_RI * NC * D * 4];
-    __shared__ double redk[LEAP_RI * NC * D * PART_K];
-    const int N = pb.N, ld = pb.ldf, b = pb.bandf, W = 2 * b + 1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ri = wave / D, d = wave - ri * D;
-    const int i = blockIdx.x * LEAP_RI + ri, ii = min(i, N - 1);
-    const int c0 = blockIdx.y * NC;
-    const size_t ro = ((size_t)d * N + ii) * ld;
-    const double *ph = pb.FH + ro, *pe = pb.FE + ro, *pt = pb.FEt + ro, *pk = pb.FK + ro;
-    const double mud = pb.mu[d];
-    const double* qc[NC];
-    const double* fc[NC];
-    double th[NC][P];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const int cc = min(c0 + c, ch.n_chains - 1);
-        qc[c] = ch.vec + vec_off(pb, cc, V_Q + ch.plan[cc].cur);
-        fc[c] = ch.vec + vec_off(pb, cc, V_F) + (size_t)d * N;
+        double xd = xin[c][0];
 #pragma unroll
-        for (int k = 0; k < P; ++k) th[c][k] = FVEC ? 0.0 : ch.par[(size_t)cc * PAR_COUNT + PAR_TH + k];
+        for (int dd = 1; dd < D; ++dd) if (d == dd) xd = xin[c][dd];
+        double val = wantf ? DR::f1(d, xin[c], thv[c]) : xd - mud;
+        if (gi >= N) val = 0.0;
+        (isrow ? vrow : vcol)[c][loc] = val;
     }
-    double ah[NC], ae[NC], at[NC], ak[NC];
+    __syncthreads();
+
+    double2 vc[NC], cacc[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { ah[c] = 0.0; ae[c] = 0.0; at[c] = 0.0; ak[c] = 0.0; }
-#pragma unroll 2
-    for (int kk = lane; kk < W; kk += 64) {
-        const int j = ii - b + kk;
-        const bool in = (j >= 0) && (j < N);
-        const int jc = min(max(j, 0), N - 1);
-        const double h = in ? ph[kk] : 0.0, e = in ? pe[kk] : 0.0, t = in ? pt[kk] : 0.0, k = in ? pk[kk] : 0.0;
+    for (int c = 0; c < NC; ++c) {
+        vc[c] = *reinterpret_cast<const double2*>(&vcol[c][2 * lane]);
+        cacc[c].x = 0.0; cacc[c].y = 0.0;
+    }
+#pragma unroll
+    for (int ck = 0; ck < NCK; ++ck) {
+        double2 (&a)[8] = (ck & 1) ? a1 : a0;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            if (FVEC) {
-                const double xc = qc[c][d * N + jc] - mud, fa = fc[c][jc];
-                ah[c] = fma(h, xc, ah[c]); ae[c] = fma(e, xc, ae[c]);
-                at[c] = fma(t, fa, at[c]); ak[c] = fma(k, fa, ak[c]);
-                continue;
+            double p[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const double2 ar = a[r];
+                p[r] = fma(ar.y, vc[c].y, ar.x * vc[c].x);
+                const double xr = vrow[c][wave * ST_RW + ck * 8 + r];
+                cacc[c].x = fma(ar.x, xr, cacc[c].x);
+                cacc[c].y = fma(ar.y, xr, cacc[c].y);
             }
-            double xa[D];
+            const double s = tsum8(p, lane);
+            // all 8 lanes of a group hold the same bits (commutative butterflies): an unconditional store keeps the loop
+            // free of branches (with them LLVM sinks the column accumulators behind the loop and the tile stays live)
+            rowout[c][wave * ST_RW + ck * 8 + (lane >> 3)] = s;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ck + 2 < NCK) {
 #pragma unroll
-            for (int dd = 0; dd < D; ++dd) xa[dd] = qc[c][dd * N + jc];
-            double xd = xa[0];
+            for (int r = 0; r < 8; ++r) a[r] = A[(size_t)((ck + 2) * 8 + r) * (TB / 2)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
-            for (int dd = 1; dd < D; ++dd) if (d == dd) xd = xa[dd];
-            const double fa = DR::f1(d, xa, th[c]);
-            const double xc = xd - mud;
-            ah[c] = fma(h, xc, ah[c]); ae[c] = fma(e, xc, ae[c]);
-            at[c] = fma(t, fa, at[c]); ak[c] = fma(k, fa, ak[c]);
+    for (int c = 0; c < NC; ++c) *reinterpret_cast<double2*>(&colacc[wave][c][2 * lane]) = cacc[c];
+    __syncthreads();
+
+    // partials: threads [0, TB) the row-type output (block row bi, slot bj), threads [TB, 2 TB) the
+    // column-type output (block row bj, slot bi; the diagonal blocks of FH / FK are complete by rows)
+    const int rvec = kind == TK_FH ? TV_HX : kind == TK_FK ? TV_KF : TV_EX;
+    const int cvec = kind == TK_FH ? TV_HX : kind == TK_FK ? TV_KF : TV_ETF;
+    const bool colout = (kind == TK_FE) || (bi != bj);
+    const size_t cstride = (size_t)4 * D * pb.nb * pb.Np;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (!act[c]) continue;
+        double* tp = ch.tpart + (size_t)(c0 + c) * cstride;
+        if (!isrow) {
+            tp[((size_t)(rvec * D + d) * pb.nb + bj) * pb.Np + bi * TB + loc] = rowout[c][loc];
+        } else if (colout) {
+            double sum = colacc[0][c][loc];
+#pragma unroll
+            for (int w = 1; w < ST_WAVES; ++w) sum += colacc[w][c][loc];
+            tp[((size_t)(cvec * D + d) * pb.nb + bi) * pb.Np + bj * TB + loc] = sum;
         }
     }
-    leap_epilogue<NC, DRIFT>(pb, ch, c0, ri, d, lane, ah, ae, at, ak, res, redk);
 }
 
-// f(X, theta) of every active chain's evaluated state -> V_F (only launched when n_chains > 1)
+// ---- point kernel (validation entry; the sampler runs the same point_block inside k_tail) ---------------------------
 template <int DRIFT>
-__global__ __launch_bounds__(256) void k_drift(DevProblem pb, DevChains ch) {
-    using DR = DriftT<DRIFT>;
+__global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains ch) {
     if (ch.gctl->all_done) return;
-    const int c = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    const LeafPlan lp = ch.plan[c];
-    if (!lp.active || i >= pb.N) return;
-    const double* q = ch.vec + vec_off(pb, c, V_Q + lp.cur);
-    double* F = ch.vec + vec_off(pb, c, V_F);
-    double x[DR::D], th[DR::P], f[DR::D];
-#pragma unroll
-    for (int d = 0; d < DR::D; ++d) x[d] = q[d * pb.N + i];
-#pragma unroll
-    for (int k = 0; k < DR::P; ++k) th[k] = ch.par[(size_t)c * PAR_COUNT + PAR_TH + k];
-    DR::f(x, th, f);
-#pragma unroll
-    for (int d = 0; d < DR::D; ++d) F[d * pb.N + i] = f[d];
+    __shared__ double res[PT_POINTS * 4 * 4];
+    __shared__ double redk[64 * PART_K];
+    if (!ch.plan[blockIdx.y].active) return;
+    point_block<DRIFT>(pb, ch, blockIdx.y, blockIdx.x, res, redk);
 }
 
 // validation / bootstrap plan: evaluate buffer 0, no leapfrog
@@ -328,37 +232,51 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_leap_finalize(DevProblem 
 }
 
 template <int NC, int DRIFT>
-int launch_leap_nd(magi_handle* h, int n_chains, hipStream_t s) {
+int launch_stream_nd(magi_handle* h, int n_chains, hipStream_t s) {
     const DevProblem& pb = h->pb;
-    const dim3 grid((pb.N + LEAP_RI - 1) / LEAP_RI + 1, (n_chains + NC - 1) / NC);      // + the service block
-    const dim3 block(64 * DriftT<DRIFT>::D * LEAP_RI);
-    constexpr bool FVEC = NC > 1;
-    if (FVEC) hipLaunchKernelGGL((k_drift<DRIFT>), dim3((pb.N + 255) / 256, n_chains), dim3(256), 0, s, pb, h->ch);
-    if (pb.bandf < 0) hipLaunchKernelGGL((k_leap_dense<NC, DRIFT, FVEC>), grid, block, 0, s, pb, h->ch);
-    else hipLaunchKernelGGL((k_leap_band<NC, DRIFT, FVEC>), grid, block, 0, s, pb, h->ch);
+    const dim3 grid(pb.n_tasks + 1, (n_chains + NC - 1) / NC);      // + the service block
+    hipLaunchKernelGGL((k_stream<NC, DRIFT>), grid, dim3(64 * ST_WAVES), 0, s, pb, h->ch);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("leap launch: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("stream launch: ") + hipGetErrorString(e));
     return MAGI_OK;
 }
 
 template <int NC>
-int launch_leap_nc(magi_handle* h, int n_chains, hipStream_t s) {
+int launch_stream_nc(magi_handle* h, int n_chains, hipStream_t s) {
     switch (h->pb.drift) {
-    case MAGI_DRIFT_SEIR3: return launch_leap_nd<NC, MAGI_DRIFT_SEIR3>(h, n_chains, s);
-    case MAGI_DRIFT_SEIR4: return launch_leap_nd<NC, MAGI_DRIFT_SEIR4>(h, n_chains, s);
-    default: return launch_leap_nd<NC, MAGI_DRIFT_SIRW>(h, n_chains, s);
+    case MAGI_DRIFT_SEIR3: return launch_stream_nd<NC, MAGI_DRIFT_SEIR3>(h, n_chains, s);
+    case MAGI_DRIFT_SEIR4: return launch_stream_nd<NC, MAGI_DRIFT_SEIR4>(h, n_chains, s);
+    default: return launch_stream_nd<NC, MAGI_DRIFT_SIRW>(h, n_chains, s);
     }
 }
 
 }  // namespace
 
-int magi_leap_wgs(const DevProblem& pb) { return (pb.N + LEAP_RI - 1) / LEAP_RI; }
+int magi_leap_wgs(const DevProblem& pb) { return (pb.N + PT_POINTS - 1) / PT_POINTS; }
+
+int magi_launch_stream(magi_handle* h, int n_chains, hipStream_t s) {
+    if (n_chains >= 3) return launch_stream_nc<4>(h, n_chains, s);
+    if (n_chains == 2) return launch_stream_nc<2>(h, n_chains, s);
+    return launch_stream_nc<1>(h, n_chains, s);
+}
+
+int magi_launch_point(magi_handle* h, int n_chains, hipStream_t s) {
+    const DevProblem& pb = h->pb;
+    const dim3 g(magi_leap_wgs(pb), n_chains), b(PT_THREADS);
+    switch (pb.drift) {
+    case MAGI_DRIFT_SEIR3: hipLaunchKernelGGL(k_point<MAGI_DRIFT_SEIR3>, g, b, 0, s, pb, h->ch); break;
+    case MAGI_DRIFT_SEIR4: hipLaunchKernelGGL(k_point<MAGI_DRIFT_SEIR4>, g, b, 0, s, pb, h->ch); break;
+    default: hipLaunchKernelGGL(k_point<MAGI_DRIFT_SIRW>, g, b, 0, s, pb, h->ch); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("point launch: ") + hipGetErrorString(e));
+    return MAGI_OK;
+}
 
 int magi_launch_leap(magi_handle* h, int n_chains, hipStream_t s) {
-    if (n_chains >= 6) return launch_leap_nc<8>(h, n_chains, s);
-    if (n_chains >= 3) return launch_leap_nc<4>(h, n_chains, s);
-    if (n_chains == 2) return launch_leap_nc<2>(h, n_chains, s);
-    return launch_leap_nc<1>(h, n_chains, s);
+    int rc = magi_launch_stream(h, n_chains, s);
+    if (rc == MAGI_OK) rc = magi_launch_point(h, n_chains, s);
+    return rc;
 }
 
 int magi_launch_plan_eval(magi_handle* h, int n_chains, hipStream_t s) {

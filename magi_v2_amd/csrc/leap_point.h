@@ -1,0 +1,156 @@
+// Point half of a leapfrog slot: everything elementwise, PT_POINTS grid points per workgroup.
+//
+// k_stream (leap.hip) has left, per chain, the block partials of the four single-phase products
+//     hx = FH xc,  ex = FE xc,  etf = FE^T f,  kf = FK f        in tpart[chain][vec][d][slot][i].
+// point_block adds them in fixed slot order and ONE lane per (grid point, component) finishes the point:
+//     Ksym r = kf - ex,   dL/dx_d = -1/2 (beta^-1 (2 hx - 2 etf + J^T 2 Ksym r)_d + dt4/dx_d)
+//     p_leaf = p_half + hs g,  rho_sub += p_leaf,  checkpoint,  U-turn partial dots,
+//     speculative next leaf:  p_half' = p_leaf + hs g,  x' = x + eps p_half'   (other buffer)
+// and leaves PART_K partial sums per workgroup for the reduce (leap_reduce.h).
+// (reference arithmetic: magi_v2.py:308-348 and the leapfrog of TFP's NoUTurnSampler)
+#pragma once
+#include "magi_internal.h"
+#include "leap_reduce.h"
+
+constexpr int PT_POINTS = 16;                  // grid points per workgroup
+constexpr int PT_THREADS = 256;                // = PT_POINTS x 4 components x 4 products
+
+template <int DRIFT>
+struct GridPoint {     // component d of grid index i of one chain (one lane)
+    using DR = DriftT<DRIFT>;
+    static constexpr int D = DR::D, P = DR::P;
+    struct Ops { double y, phe, rhoe, cpk[4], crk[4], x[D], th[P], sig2; };
+
+    // the lane's own operands: independent of the products, so their latency overlaps the partial sums
+    static __device__ __forceinline__ Ops load(const DevProblem& pb, const DevChains& ch, const LeafPlan& lp, int cc, int i, int d) {
+        Ops o;
+        const int N = pb.N, dimp = pb.dimp;
+        const double* vb = ch.vec + vec_off(pb, cc, 0);
+        const double* par = ch.par + (size_t)cc * PAR_COUNT;
+        const double* q = vb + (size_t)(V_Q + lp.cur) * dimp;
+        const int e = d * N + i;
+        o.y = pb.yobs[e];
+        o.phe = 0.0; o.rhoe = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o.cpk[k] = 0.0; o.crk[k] = 0.0; }
+        if (lp.leaf) {
+            o.phe = (vb + (size_t)(V_P + lp.cur) * dimp)[e];
+            o.rhoe = (vb + (size_t)V_RHOSUB * dimp)[e];
+            const double* ckp = vb + (size_t)V_CKP0 * dimp;
+            const double* ckr = vb + (size_t)V_CKRHO0 * dimp;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < lp.nchk) { o.cpk[k] = ckp[(size_t)lp.chk_slot[k] * dimp + e]; o.crk[k] = ckr[(size_t)lp.chk_slot[k] * dimp + e]; }
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) o.th[k] = par[PAR_TH + k];
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) o.x[dd] = q[dd * N + i];
+        o.sig2 = par[PAR_SIG2 + d];
+        return o;
+    }
+
+    static __device__ __forceinline__ void finish(const DevProblem& pb, const DevChains& ch, const LeafPlan& lp, int cc, int i, int d, const Ops& o,
+                                                  const double* res /* [D][4] */, double* pk /* [PART_K] */) {
+#pragma unroll
+        for (int k = 0; k < PART_K; ++k) pk[k] = 0.0;
+        const int N = pb.N, dimp = pb.dimp;
+        double* vb = ch.vec + vec_off(pb, cc, 0);
+        const int e = d * N + i;
+        double f[D], g2[D], jt[D], tp[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) tp[k] = 0.0;
+        DR::f(o.x, o.th, f);
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) g2[dd] = 2.0 * (res[dd * 4 + TV_KF] - res[dd * 4 + TV_EX]);
+        DR::jt(o.x, o.th, g2, jt, tp);
+        // select this lane's component
+        double xd = o.x[0], fd = f[0], jtd = jt[0], mud = pb.mu[0];
+#pragma unroll
+        for (int dd = 1; dd < D; ++dd) if (d == dd) { xd = o.x[dd]; fd = f[dd]; jtd = jt[dd]; mud = pb.mu[dd]; }
+        const double hx = res[d * 4 + TV_HX], ex = res[d * 4 + TV_EX], etf = res[d * 4 + TV_ETF], kf = res[d * 4 + TV_KF];
+        pk[PK_T12] = (xd - mud) * hx + fd * (kf - 2.0 * ex);
+        if (d == 0) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) pk[PK_TP + k] = tp[k];
+        }
+        double d4 = 0.0;
+        if (!isnan(o.y)) {
+            const double df = xd - o.y;
+            pk[PK_SS + d] = df * df;
+            d4 = 2.0 * df / o.sig2;
+        }
+        const double gx = -0.5 * (pb.beta_inv * (2.0 * hx - 2.0 * etf + jtd) + d4);
+        st_agent(vb + (size_t)V_G * dimp + e, gx);
+        if (lp.leaf) {
+            double* rho = vb + (size_t)V_RHOSUB * dimp;
+            double* ckp = vb + (size_t)V_CKP0 * dimp;
+            double* ckr = vb + (size_t)V_CKRHO0 * dimp;
+            const double pn = o.phe + lp.hs * gx;
+            st_agent(vb + (size_t)V_PLEAF * dimp + e, pn);
+            const double rs = o.rhoe + pn;
+            st_agent(rho + e, rs);
+            pk[PK_PP] = pn * pn;
+            if (lp.even) { st_agent(ckp + (size_t)lp.ck_slot * dimp + e, pn); st_agent(ckr + (size_t)lp.ck_slot * dimp + e, rs); }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < lp.nchk) { const double df = rs - o.crk[k]; pk[PK_DOT + 2 * k] = df * o.cpk[k]; pk[PK_DOT + 2 * k + 1] = df * pn; }
+            const double pnext = pn + lp.hs * gx;
+            st_agent(vb + (size_t)(V_P + (lp.cur ^ 1)) * dimp + e, pnext);
+            st_agent(vb + (size_t)(V_Q + (lp.cur ^ 1)) * dimp + e, xd + lp.eps * pnext);
+        }
+    }
+};
+
+// All PT_THREADS threads of the block must call it.  res: PT_POINTS*4*4 doubles, redk: 64*PART_K doubles of LDS.
+// Writes part[cc][k][blk].  The chain's plan must be active.
+template <int DRIFT>
+__device__ __forceinline__ void point_block(const DevProblem& pb, const DevChains& ch, int cc, int blk, double* res, double* redk) {
+    using GP = GridPoint<DRIFT>;
+    constexpr int D = GP::D, TB = MAGI_TB;
+    const int t = threadIdx.x;
+    const LeafPlan lp = ch.plan[cc];
+    // finishing lanes: t < 64 = (component, point)
+    const int fpt = t & (PT_POINTS - 1), fd = (t >> 4) & 3;
+    const int fi = blk * PT_POINTS + fpt;
+    const bool fvalid = (t < 64) && (fd < D) && (fi < pb.N);
+    typename GP::Ops ops;
+    if (fvalid) ops = GP::load(pb, ch, lp, cc, fi, fd);
+    // product lanes: t = (component, product, point)
+    {
+        const int pt = t & (PT_POINTS - 1), v = (t >> 4) & 3, d = t >> 6;
+        const int i = blk * PT_POINTS + pt;
+        double sum = 0.0;
+        if (d < D && i < pb.N) {
+            const int b = i / TB, s0 = max(0, b - pb.wb), s1 = min(pb.nb - 1, b + pb.wb);
+            const double* src = ch.tpart + (size_t)cc * 4 * D * pb.nb * pb.Np + ((size_t)(v * D + d) * pb.nb) * pb.Np + i;
+            int sl = s0;
+            for (; sl + 7 <= s1; sl += 8) {
+                double u[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) u[k] = src[(size_t)(sl + k) * pb.Np];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sum += u[k];
+            }
+            for (; sl <= s1; ++sl) sum += src[(size_t)sl * pb.Np];
+        }
+        res[(pt * 4 + d) * 4 + v] = sum;
+    }
+    __syncthreads();
+    if (t < 64) {
+        double* pk = redk + (size_t)t * PART_K;
+        if (fvalid) {
+            GP::finish(pb, ch, lp, cc, fi, fd, ops, res + fpt * 16, pk);
+        } else {
+#pragma unroll
+            for (int k = 0; k < PART_K; ++k) pk[k] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (t < PART_K) {
+        double s = 0.0;
+#pragma unroll 8
+        for (int u = 0; u < 64; ++u) s += redk[u * PART_K + t];
+        st_agent(&ch.part[((size_t)cc * PART_K + t) * ch.n_wg + blk], s);
+    }
+}

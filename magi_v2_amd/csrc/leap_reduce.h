@@ -13,8 +13,13 @@
 #include "magi_internal.h"
 
 #ifdef MAGI_TAIL_STAMPS
-#define MAGI_STAMP(par, i) do { if (threadIdx.x == 0) (par)[40 + (i)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
+// timing stamps (dev builds): staged in LDS, copied to par[40..55] only when a HOT leaf finishes, so a run that
+// ends on a slow path still reports the last hot leaf
+static __shared__ double g_stamps[16];
+#define MAGI_STAMP(par, i) do { if (threadIdx.x == 0) g_stamps[(i)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define MAGI_STAMP_FLUSH(par) do { if (threadIdx.x == 0) for (int _i = 0; _i < 16; ++_i) (par)[40 + _i] = g_stamps[_i]; } while (0)
 #else
+#define MAGI_STAMP_FLUSH(par) do { } while (0)
 #define MAGI_STAMP(par, i) do { } while (0)
 #endif
 
@@ -65,15 +70,15 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
     for (int k = 0; k < K0 + 8; ++k) red[k] = 0.0;
     const bool dots = leaf && lp.nchk > 0;
     for (int w = threadIdx.x; w < nwg; w += blockDim.x) {
-        red[0] += part[(size_t)PK_T12 * nwg + w];
+        red[0] += ld_agent(&part[(size_t)PK_T12 * nwg + w]);
 #pragma unroll
-        for (int d = 0; d < D; ++d) red[1 + d] += part[(size_t)(PK_SS + d) * nwg + w];
+        for (int d = 0; d < D; ++d) red[1 + d] += ld_agent(&part[(size_t)(PK_SS + d) * nwg + w]);
 #pragma unroll
-        for (int k = 0; k < P; ++k) red[1 + D + k] += part[(size_t)(PK_TP + k) * nwg + w];
-        red[1 + D + P] += part[(size_t)PK_PP * nwg + w];
+        for (int k = 0; k < P; ++k) red[1 + D + k] += ld_agent(&part[(size_t)(PK_TP + k) * nwg + w]);
+        red[1 + D + P] += ld_agent(&part[(size_t)PK_PP * nwg + w]);
         if (dots) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) red[K0 + k] += part[(size_t)(PK_DOT + k) * nwg + w];
+            for (int k = 0; k < 8; ++k) red[K0 + k] += ld_agent(&part[(size_t)(PK_DOT + k) * nwg + w]);
         }
     }
     if (dots) {

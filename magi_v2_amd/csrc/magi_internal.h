@@ -14,7 +14,7 @@
 #define MAGI_MAX_D 4        // compiled-in drifts have D <= 4, P <= 5
 #define MAGI_MAX_P 6
 #define MAGI_MAX_DEPTH 12   // checkpoint slots for the iterative NUTS U-turn checks
-#define MAGI_TAIL_THREADS 512
+#define MAGI_TAIL_THREADS 256
 #define MAGI_WAVE 64
 
 // ------------------------------------------------------------------------------------------
@@ -37,11 +37,18 @@ struct DevProblem {
     const double* Mt;     // [D][N][ld]  m^T
     const double* Ksym;   // [D][N][ld]  (K^-1 + K^-T)/2
     const double* yobs;   // [D][N], NaN = not observed        (magi_v2.py:96-100)
-    // single-phase ("fused") operators of the sampler, [D][N][ldf] each (see logpost.hip):
-    //   FH = Csym + m^T Ksym m,  FE = Ksym m,  FEt = FE^T,  FK = Ksym
-    const double *FH, *FE, *FEt, *FK;
-    int ldf;       // row pitch of the fused stacks; even
-    int bandf;     // -1 dense; else half-width 3b (products of band-b matrices)
+    // single-phase ("fused") operators of the sampler (see leap.hip / pack.hip):
+    //   FH = Csym + m^T Ksym m (symmetric),  FE = Ksym m,  FK = Ksym (symmetric)
+    // stored as packed TB x TB blocks, one per task: the lower block triangle of FH and FK (a block
+    // serves A x and A^T x in one pass), every block of FE (serves FE xc and FE^T f) -- 2 N^2 D values
+    // instead of the 4 N^2 D of four row-major stacks.
+    const double* tiles;   // [n_tasks][TB][TB]
+    const int* tasks;      // [n_tasks][4] = {d, kind, bi, bj}
+    int n_tasks;
+    int nb;        // blocks per side, ceil(N / TB)
+    int Np;        // nb * TB
+    int wb;        // block half-band: blocks with |bi - bj| <= wb exist (nb when dense)
+    int bandf;     // -1 dense; else half-width 3b of the fused operators (products of band-b matrices)
 };
 
 // Per-chain vector slots (each dimp doubles) -------------------------------------------------
@@ -56,7 +63,7 @@ enum VecSlot {
     V_R,         // f - m xc            [D][N]
     V_KR,        // Ksym * r            [D][N]   (fused path: Ksym * f)
     V_ETF,       // (validation kernels only)
-    V_F,         // drift f(X, theta) of the evaluated state [D][N]; filled by k_drift when n_chains > 1
+    V_F,         // (unused)
     V_PL, V_QL, V_GL,       // left end of the trajectory
     V_PR, V_QR, V_GR,       // right end
     V_CANDQ, V_CANDG,       // trajectory-level proposal
@@ -136,14 +143,20 @@ struct LeafPlan {
     unsigned long long seed;
 };
 
+constexpr int MAGI_TB = 128;  // block edge of the packed single-phase operators
+enum TileKind { TK_FH = 0, TK_FK = 1, TK_FE = 2 };
+enum TileVec { TV_HX = 0, TV_EX = 1, TV_ETF = 2, TV_KF = 3 };
+
 constexpr int PART_K = 24;   // partial sums per workgroup and chain: t12, ss[D], tp[P], pp, 4 x (dA, dB)
 
 struct DevChains {
     double* vec;          // [n_chains][V_COUNT][dimp]
     ChainCtl* ctl;        // [n_chains]
     LeafPlan* plan;       // [n_chains]
-    double* part;         // [n_chains][PART_K][n_wg] partial sums of the streaming kernel
-    int n_wg;             // workgroups along the grid axis of k_leap_*
+    double* part;         // [n_chains][PART_K][n_wg] partial sums of the point kernel
+    int n_wg;             // workgroups along the grid axis of k_point
+    int* ticket;          // [n_chains] workgroups of k_tail that have finished the point half of the slot
+    double* tpart;        // [n_chains][4 (hx, ex, etf, kf)][D][nb][Np] block partials of the streaming kernel
     double* par;          // [n_chains][PAR_COUNT] transformed parameters of the state in V_Q
     GlobalCtl* gctl;
     int n_chains;
@@ -162,6 +175,15 @@ struct DevChains {
 __host__ __device__ inline size_t vec_off(const DevProblem& pb, int chain, int slot) {
     return ((size_t)chain * V_COUNT + (size_t)slot) * (size_t)pb.dimp;
 }
+
+// ------------------------------------------------------------------------------------------
+// Agent-scope accesses for data exchanged between workgroups INSIDE one kernel (k_tail: point workgroups ->
+// the workgroup that finishes last).  The L2 of each XCD is not coherent with the others: a write-through
+// store (sc1) lands at the device coherence point without a whole-L2 write-back fence, and an sc1 load
+// does not hit a stale line.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011), identical to oracle/magi_oracle.py::philox4x32
@@ -623,8 +645,9 @@ struct magi_handle {
     DevProblem pb{};
     double *dCsym = nullptr, *dM = nullptr, *dMt = nullptr, *dKsym = nullptr, *dYobs = nullptr;
     size_t mat_elems = 0;
-    double *dFH = nullptr, *dFE = nullptr, *dFEt = nullptr, *dFK = nullptr;
-    size_t fused_elems = 0;
+    double* dTiles = nullptr;
+    int* dTasks = nullptr;
+    size_t tiles_cap = 0, tasks_cap = 0;
 
     // chains
     int n_chains = 0;
@@ -665,7 +688,9 @@ int magi_fail(magi_handle* h, int code, const std::string& msg);
 int magi_launch_gradient(magi_handle* h, int n_chains, hipStream_t s);        // phases 1-3
 int magi_launch_phase(magi_handle* h, int phase, int n_chains, hipStream_t s);
 int magi_launch_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s);
-int magi_launch_leap(magi_handle* h, int n_chains, hipStream_t s);             // single-phase mat-vecs + leapfrog epilogue
+int magi_launch_leap(magi_handle* h, int n_chains, hipStream_t s);             // k_stream + k_point
+int magi_launch_stream(magi_handle* h, int n_chains, hipStream_t s);           // single-phase block mat-vecs
+int magi_launch_point(magi_handle* h, int n_chains, hipStream_t s);            // leapfrog epilogue per grid point
 int magi_launch_leap_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s);
 int magi_leap_wgs(const DevProblem& pb);
 int magi_build_profile_get(double* flops, double* ms, long* calls);           // build.hip

@@ -7,6 +7,8 @@
 //                 (zeros where the column falls outside [0, N)).  Used when 2b+1 < N.
 #include "magi_internal.h"
 
+#include <algorithm>
+
 namespace {
 
 enum PackMode { PACK_SYM = 0, PACK_COPY = 1, PACK_TRANS = 2 };
@@ -28,6 +30,22 @@ __global__ void k_pack(const double* __restrict__ src, double* __restrict__ dst,
         else v = 0.5 * (a + A[(size_t)j * N + i]);
     }
     dst[((size_t)d * N + i) * ld + k] = v;
+}
+
+// one TB x TB block of FH / FK / FE per workgroup -> packed tile storage, zero beyond N and beyond the band
+__global__ __launch_bounds__(256) void k_pack_tiles(const double* __restrict__ H, const double* __restrict__ K, const double* __restrict__ E,
+                                                    const int* __restrict__ tasks, double* __restrict__ tiles, int N, int fb) {
+    const int t = blockIdx.x;
+    const int d = tasks[4 * t], kind = tasks[4 * t + 1], bi = tasks[4 * t + 2], bj = tasks[4 * t + 3];
+    const double* A = (kind == TK_FH ? H : kind == TK_FK ? K : E) + (size_t)d * N * N;
+    double* T = tiles + (size_t)t * MAGI_TB * MAGI_TB;
+    for (int e = threadIdx.x; e < MAGI_TB * MAGI_TB; e += 256) {
+        const int r = e / MAGI_TB, c = e - r * MAGI_TB;
+        const int i = bi * MAGI_TB + r, j = bj * MAGI_TB + c;
+        double v = 0.0;
+        if (i < N && j < N && (fb < 0 || abs(i - j) <= fb)) v = A[(size_t)i * N + j];
+        T[e] = v;
+    }
 }
 
 }  // namespace
@@ -62,26 +80,37 @@ int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double*
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("pack launch: ") + hipGetErrorString(e));
 
     // ---- single-phase operators of the sampler ----------------------------------------------------
-    //   t1 + t2 = xc^T FH xc - 2 f^T FE xc + f^T FK f,   FH = Csym + m^T Ksym m,  FE = Ksym m
+    //   t1 + t2 = xc^T FH xc - 2 f^T FE xc + f^T FK f,   FH = Csym + m^T Ksym m,  FE = Ksym m,  FK = Ksym
     // formed from the MASKED matrices, so the reference's band semantics carry over exactly: the
-    // products of band-b matrices have band <= 3b and are stored without truncation.
+    // products of band-b matrices have band <= 3b, and only blocks that intersect that band are kept.
     {
-        const bool fbanded = bandsize >= 0 && (6 * bandsize + 1) < N;
-        const int fW = fbanded ? 6 * bandsize + 1 : N;
-        const int ldf = (fW + 1) & ~1;
-        const size_t felems = (size_t)D * N * ldf;
-        if (felems != h->fused_elems || !h->dFH) {
-            if (h->dFH) (void)hipFree(h->dFH);
-            if (h->dFE) (void)hipFree(h->dFE);
-            if (h->dFEt) (void)hipFree(h->dFEt);
-            if (h->dFK) (void)hipFree(h->dFK);
-            h->dFH = h->dFE = h->dFEt = h->dFK = nullptr;
-            MAGI_HIP_CHECK(h, hipMalloc(&h->dFH, felems * sizeof(double)));
-            MAGI_HIP_CHECK(h, hipMalloc(&h->dFE, felems * sizeof(double)));
-            MAGI_HIP_CHECK(h, hipMalloc(&h->dFEt, felems * sizeof(double)));
-            MAGI_HIP_CHECK(h, hipMalloc(&h->dFK, felems * sizeof(double)));
-            h->fused_elems = felems;
+        const int fb = (bandsize >= 0 && (6 * bandsize + 1) < N) ? 3 * bandsize : -1;
+        const int nb = (N + MAGI_TB - 1) / MAGI_TB;
+        const int wb = fb < 0 ? nb : std::min(nb, (std::max(fb, 1) - 1) / MAGI_TB + 1);
+        std::vector<int> tasks;
+        for (int d = 0; d < D; ++d)
+            for (int kind = 0; kind < 3; ++kind)
+                for (int bi = 0; bi < nb; ++bi)
+                    for (int bj = 0; bj < nb; ++bj) {
+                        if (kind != TK_FE && bj > bi) continue;            // symmetric: lower block triangle
+                        if (std::abs(bi - bj) > wb) continue;
+                        tasks.push_back(d); tasks.push_back(kind); tasks.push_back(bi); tasks.push_back(bj);
+                    }
+        const int n_tasks = (int)(tasks.size() / 4);
+        const size_t telems = (size_t)n_tasks * MAGI_TB * MAGI_TB;
+        if (telems > h->tiles_cap) {
+            if (h->dTiles) (void)hipFree(h->dTiles);
+            h->dTiles = nullptr; h->tiles_cap = 0;
+            MAGI_HIP_CHECK(h, hipMalloc(&h->dTiles, telems * sizeof(double)));
+            h->tiles_cap = telems;
         }
+        if (tasks.size() > h->tasks_cap) {
+            if (h->dTasks) (void)hipFree(h->dTasks);
+            h->dTasks = nullptr; h->tasks_cap = 0;
+            MAGI_HIP_CHECK(h, hipMalloc(&h->dTasks, tasks.size() * sizeof(int)));
+            h->tasks_cap = tasks.size();
+        }
+        MAGI_HIP_CHECK(h, hipMemcpyAsync(h->dTasks, tasks.data(), tasks.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
         const size_t nn = (size_t)D * N * N;
         double *tCs = nullptr, *tM = nullptr, *tKs = nullptr, *tE = nullptr;
         MAGI_HIP_CHECK(h, hipMalloc(&tCs, nn * sizeof(double)));
@@ -94,22 +123,21 @@ int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double*
         hipLaunchKernelGGL(k_pack<PACK_SYM>, gd, block, 0, h->stream, dK_inv, tKs, N, N, mask, 0);
         int rc = magi_fused_operators(h, N, D, tCs, tM, tKs, tE);
         if (rc == MAGI_OK) {
-            const int fb = fbanded ? 3 * bandsize : -1;
-            dim3 gf((ldf + 255) / 256, N, D);
-            hipLaunchKernelGGL(k_pack<PACK_COPY>, gf, block, 0, h->stream, tCs, h->dFH, N, ldf, fb, fbanded ? 1 : 0);
-            hipLaunchKernelGGL(k_pack<PACK_COPY>, gf, block, 0, h->stream, tE, h->dFE, N, ldf, fb, fbanded ? 1 : 0);
-            hipLaunchKernelGGL(k_pack<PACK_TRANS>, gf, block, 0, h->stream, tE, h->dFEt, N, ldf, fb, fbanded ? 1 : 0);
-            hipLaunchKernelGGL(k_pack<PACK_COPY>, gf, block, 0, h->stream, tKs, h->dFK, N, ldf, fb, fbanded ? 1 : 0);
+            hipLaunchKernelGGL(k_pack_tiles, dim3(n_tasks), dim3(256), 0, h->stream, tCs, tKs, tE, h->dTasks, h->dTiles, N, fb);
             e = hipGetLastError();
         }
-        hipError_t se = hipStreamSynchronize(h->stream);
+        hipError_t se = hipStreamSynchronize(h->stream);     // (also keeps `tasks` alive until the copy is done)
         (void)hipFree(tCs); (void)hipFree(tM); (void)hipFree(tKs); (void)hipFree(tE);
         if (rc) return rc;
         if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("fused pack launch: ") + hipGetErrorString(e));
         if (se != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("fused pack: ") + hipGetErrorString(se));
-        pb.FH = h->dFH; pb.FE = h->dFE; pb.FEt = h->dFEt; pb.FK = h->dFK;
-        pb.ldf = ldf;
-        pb.bandf = fbanded ? 3 * bandsize : -1;
+        pb.tiles = h->dTiles;
+        pb.tasks = h->dTasks;
+        pb.n_tasks = n_tasks;
+        pb.nb = nb;
+        pb.Np = nb * MAGI_TB;
+        pb.wb = wb;
+        pb.bandf = fb;
     }
 
     pb.N = N;

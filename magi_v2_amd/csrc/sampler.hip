@@ -7,8 +7,9 @@
 // U-turn test, max_tree_depth 10, max_energy_diff 1000; Nesterov dual averaging) is restated in
 // oracle/magi_oracle.py and mirrored here decision for decision, with a shared Philox4x32-10 RNG.
 //
-// MI355X design: a leapfrog is the static kernel pair [single-phase mat-vecs, tail].  The tail
-// (one 512-thread workgroup per chain) assembles the gradient, completes the momentum update, does
+// MI355X design: a leapfrog is the static kernel pair [k_stream (single-phase block mat-vecs), k_tail].
+// k_tail runs the point half of the slot (leap_point.h) on N/16 workgroups per chain; the workgroup
+// that finishes last (ticket counter) adds the partial sums, finishes the parameter entries, does
 // all tree bookkeeping (multinomial proposal, checkpointed U-turn tests, doubling, merge,
 // transition end, dual averaging, temperature, next momentum draw) and writes the NEXT position
 // to evaluate.  No decision ever returns to the host, so the host only replays one hipGraph of
@@ -21,6 +22,7 @@
 // transition-end work sits behind one branch at the bottom.
 #include "magi_internal.h"
 #include "leap_reduce.h"
+#include "leap_point.h"
 
 namespace {
 
@@ -92,13 +94,42 @@ __device__ __forceinline__ LeafPlan make_leaf_plan(const ChainCtl& c, unsigned l
 }
 
 template <int DRIFT>
-__global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevChains ch, SamplerCfgDev cfg) {
+__global__ __launch_bounds__(PT_THREADS) void k_tail(DevProblem pb, DevChains ch, SamplerCfgDev cfg) {
     __shared__ double sh[25 * 16];
     __shared__ double shs[24];
+    __shared__ double pres[PT_POINTS * 4 * 4];
+    __shared__ double predk[64 * PART_K];
+    __shared__ int s_last;
     if (ch.gctl->all_done) return;
-    const int chain = blockIdx.x;
+    const int chain = blockIdx.y;
     const int tid = threadIdx.x;
+#ifdef MAGI_TAIL_STAMPS
+    const double st_entry = (double)__builtin_amdgcn_s_memrealtime();
+#endif
+    // ---- point half of the slot on every workgroup; the LAST one to finish goes on to the decisions -------------
+    if (ch.plan[chain].active) point_block<DRIFT>(pb, ch, chain, blockIdx.x, pres, predk);
+#ifdef MAGI_TAIL_STAMPS
+    const double st_point = (double)__builtin_amdgcn_s_memrealtime();
+#endif
+    // every global store of point_block is write-through (st_agent): once this workgroup's stores are acknowledged
+    // (workgroup-scope release = wait for them) the ticket may be taken; no whole-L2 write-back on the hot path
+#ifdef MAGI_FULL_FENCE
+    __threadfence();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#endif
+    __syncthreads();
+    if (tid == 0) s_last = (__hip_atomic_fetch_add(&ch.ticket[chain], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) ch.ticket[chain] = 0;
+#ifdef MAGI_FULL_FENCE
+    __threadfence();
+#endif
     MAGI_STAMP(ch.par + (size_t)chain * PAR_COUNT, 0);
+#ifdef MAGI_TAIL_STAMPS
+    if (tid == 0) { g_stamps[8] = st_entry; g_stamps[9] = st_point; g_stamps[7] = ch.par[(size_t)chain * PAR_COUNT + 40 + 7]; g_stamps[10] = ch.par[(size_t)chain * PAR_COUNT + 40 + 10]; }
+#endif
     ChainCtl c = ch.ctl[chain];
     const int dim = pb.dim;
     const int stop_k = min(ch.gctl->stop_k, cfg.total);
@@ -109,6 +140,11 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
     const size_t sv = pb.dimp;
 
     bool do_sample = false, do_doubling = false;     // what to set up before returning
+    // The hot path reads of other workgroups' output are the partial sums (ld_agent).  Every other path that reads the
+    // vectors the point workgroups have just written (V_G, V_PLEAF, V_RHOSUB, checkpoints) first invalidates this
+    // XCD's caches; the writers' stores are write-through, so no release fence is needed on their side.
+    bool acquired = false;
+#define TAIL_ACQUIRE() do { if (!acquired) { __threadfence(); acquired = true; } } while (0)
     const bool hmc = cfg.mode == MAGI_MODE_HMC;       // fixed-L HMC: one forward "subtree" of L leaves, Metropolis at its end
 
     if (c.phase == PH_IDLE) {
@@ -141,6 +177,7 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
 
         if (!leaf) {
             // bootstrap_results: target / gradient at the initial state, cached at beta_temp(0)
+            TAIL_ACQUIRE();
             for (int e = tid; e < dim; e += blockDim.x) { v.candq[e] = qcur[e]; v.candg[e] = v.g[e]; }
             c.cand_L = L;
             c.beta_cache = shs[16];
@@ -157,6 +194,7 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k < nk) no_u = no_u && (ro.dA[k] > 0.0) && (ro.dB[k] > 0.0);
+            if (nk >= 5) TAIL_ACQUIRE();
             for (int kk = 5; kk <= nk; ++kk) {       // one leaf in 32 gets here
                 const int left = it + 1 - (1 << kk);
                 const double* cp = v.ckp + (size_t)__popc((unsigned)left) * sv;
@@ -194,19 +232,23 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_tail(DevProblem pb, DevCh
 
             if (c.it < c.nsteps && c.cont) {
                 // ---- the speculative next leaf stands: flip buffers, publish its plan -------------------------
-                if (accept_leaf)                     // proposal copy (expected O(log n) times per subtree)
+                if (accept_leaf) {                   // proposal copy (expected O(log n) times per subtree)
+                    TAIL_ACQUIRE();
                     for (int e = tid; e < dim; e += blockDim.x) { v.subq[e] = qcur[e]; v.subg[e] = v.g[e]; }
+                }
                 c.cur = lp.cur ^ 1;
                 if (tid == 0) {
                     ch.plan[chain] = make_leaf_plan(c, cfg.seed, hmc);
                     ch.ctl[chain] = c;
                 }
                 MAGI_STAMP(par, 6);
+                MAGI_STAMP_FLUSH(par);
                 return;
             }
 
             // ---- subtree finished: merge into the trajectory (biased progressive sampling); for HMC the
             //      "subtree" is the whole trajectory and the merge is the Metropolis test on its last state ----
+            TAIL_ACQUIRE();
             const double tree_weight = c.cont ? c.sub_weight : -INFINITY;
             if (tid == 0) shs[20] = hmc ? 0.0 : logaddexp(tree_weight, c.cand_weight);
             const double thresh = hmc ? ediff : tree_weight - c.cand_weight;
@@ -385,7 +427,7 @@ __global__ void k_init_chains(DevChains ch, SamplerCfgDev cfg, const long long* 
 }  // namespace
 
 int magi_launch_tail(magi_handle* h, int n_chains, hipStream_t s) {
-    const dim3 g(n_chains), b(MAGI_TAIL_THREADS);
+    const dim3 g(h->ch.n_wg, n_chains), b(PT_THREADS);
     switch (h->pb.drift) {
     case MAGI_DRIFT_SEIR3: hipLaunchKernelGGL(k_tail<MAGI_DRIFT_SEIR3>, g, b, 0, s, h->pb, h->ch, h->cfg); break;
     case MAGI_DRIFT_SEIR4: hipLaunchKernelGGL(k_tail<MAGI_DRIFT_SEIR4>, g, b, 0, s, h->pb, h->ch, h->cfg); break;

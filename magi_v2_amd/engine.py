@@ -290,7 +290,7 @@ class MagiEngine:
     # -- instrumentation ------------------------------------------------------------------------
     def time_gradient(self, n_chains=1, reps=50):
         total = C.c_double(0.0)
-        ph = np.zeros(6)
+        ph = np.zeros(8)
         self._check(self._lib.magi_time_gradient(self._h, int(n_chains), int(reps), C.byref(total), _ptr(ph)))
         return total.value, ph
 
@@ -310,6 +310,6 @@ class MagiEngine:
         return out
 
     def gradient_bytes(self, n_chains=1):
-        b = np.zeros(6)
+        b = np.zeros(8)
         self._check(self._lib.magi_gradient_bytes(self._h, int(n_chains), _ptr(b)))
         return b
