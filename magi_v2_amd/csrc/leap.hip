@@ -69,7 +69,10 @@ __device__ __forceinline__ double tsum8(const double (&v)[8], int lane) {
     return w;
 }
 
-constexpr int ST_WAVES = 4;                    // waves per block task
+#ifndef MAGI_ST_WAVES
+#define MAGI_ST_WAVES 4
+#endif
+constexpr int ST_WAVES = MAGI_ST_WAVES;        // waves per block task
 constexpr int ST_RW = MAGI_TB / ST_WAVES;      // rows of the block per wave
 
 // ---- streaming kernel: one TB x TB block of FH / FK / FE per workgroup ----------------------------------
@@ -80,7 +83,7 @@ constexpr int ST_RW = MAGI_TB / ST_WAVES;      // rows of the block per wave
 // where v is xc = X_d - mu_d or f_d = drift_d(X, theta) as the operator requires (evaluated on the fly from the
 // state vector).  The partials go to tpart[chain][vec][d][other block][i]; k_point adds them in fixed order.
 template <int NC, int DRIFT>
-__global__ __launch_bounds__(64 * ST_WAVES) __attribute__((amdgpu_waves_per_eu(NC == 1 ? 4 : NC == 2 ? 3 : 2))) void k_stream(DevProblem pb, DevChains ch) {
+__global__ __launch_bounds__(64 * ST_WAVES) __attribute__((amdgpu_waves_per_eu(ST_WAVES == 8 ? (NC <= 2 ? 4 : 2) : (NC == 1 ? 4 : NC == 2 ? 3 : 2)))) void k_stream(DevProblem pb, DevChains ch) {
     using DR = DriftT<DRIFT>;
     constexpr int D = DR::D, P = DR::P, TB = MAGI_TB;
     if (ch.gctl->all_done) return;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) __attribute__((amdgpu_waves_per_eu(N
     // operands of this thread's vector entry (issued before the tile stream so that their wait does not
     // cover the 32 row loads behind them)
     const bool isrow = t >= TB;
-    const int loc = isrow ? t - TB : t;
+    const int loc = (isrow ? t - TB : t) & (TB - 1);
     const int gi = (isrow ? bi : bj) * TB + loc;
     const bool wantf = isrow ? (kind != TK_FH) : (kind == TK_FK);
     const double mud = sel4(pb.mu, d);
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) __attribute__((amdgpu_waves_per_eu(N
         for (int dd = 1; dd < D; ++dd) if (d == dd) xd = xin[c][dd];
         double val = wantf ? DR::f1(d, xin[c], thv[c]) : xd - mud;
         if (gi >= N) val = 0.0;
-        (isrow ? vrow : vcol)[c][loc] = val;
+        if (t < 2 * TB) (isrow ? vrow : vcol)[c][loc] = val;
     }
     __syncthreads();
 
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) __attribute__((amdgpu_waves_per_eu(N
     const size_t cstride = (size_t)4 * D * pb.nb * pb.Np;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        if (!act[c]) continue;
+        if (!act[c] || t >= 2 * TB) continue;
         double* tp = ch.tpart + (size_t)(c0 + c) * cstride;
         if (!isrow) {
             tp[((size_t)(rvec * D + d) * pb.nb + bj) * pb.Np + bi * TB + loc] = rowout[c][loc];

@@ -63,33 +63,25 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
             if (k < lp.nchk) { cpj[k] = ckp[(size_t)lp.chk_slot[k] * dimp + ND + j]; crj[k] = ckr[(size_t)lp.chk_slot[k] * dimp + ND + j]; }
     }
 
-    // ---- add the workgroup partials ------------------------------------------------------------
-    constexpr int K0 = 2 + D + P;            // t12, ss, tp, pp
+    // ---- add the workgroup partials: wave w owns values k = w, w + nw, ...; lane = workgroup (fixed order) ---------
+    constexpr int K0 = 2 + D + P;            // t12, ss, tp, pp  (layout of red[]: [0] t12, [1..D] ss, [1+D..] tp, [1+D+P] pp, [K0..] dots)
     double red[K0 + 8];
-#pragma unroll
-    for (int k = 0; k < K0 + 8; ++k) red[k] = 0.0;
     const bool dots = leaf && lp.nchk > 0;
-    for (int w = threadIdx.x; w < nwg; w += blockDim.x) {
-        red[0] += ld_agent(&part[(size_t)PK_T12 * nwg + w]);
-#pragma unroll
-        for (int d = 0; d < D; ++d) red[1 + d] += ld_agent(&part[(size_t)(PK_SS + d) * nwg + w]);
-#pragma unroll
-        for (int k = 0; k < P; ++k) red[1 + D + k] += ld_agent(&part[(size_t)(PK_TP + k) * nwg + w]);
-        red[1 + D + P] += ld_agent(&part[(size_t)PK_PP * nwg + w]);
-        if (dots) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) red[K0 + k] += ld_agent(&part[(size_t)(PK_DOT + k) * nwg + w]);
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        const int nval = dots ? K0 + 8 : K0;
+        for (int k = wave; k < nval; k += nw) {
+            // red index -> PART row
+            const int row = (k == 0) ? PK_T12 : (k <= D) ? PK_SS + (k - 1) : (k <= D + P) ? PK_TP + (k - 1 - D) : (k == 1 + D + P) ? PK_PP : PK_DOT + (k - K0);
+            double v = 0.0;
+            for (int w = lane; w < nwg; w += 64) v += ld_agent(&part[(size_t)row * nwg + w]);
+            v = wave_sum(v);
+            if (lane == 0) sh[k] = v;
         }
-    }
-    if (dots) {
-        block_sum<K0 + 8>(red, sh);
-    } else {
-        double r0[K0];
+        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < K0; ++k) r0[k] = red[k];
-        block_sum<K0>(r0, sh);
-#pragma unroll
-        for (int k = 0; k < K0; ++k) red[k] = r0[k];
+        for (int k = 0; k < K0 + 8; ++k) red[k] = (k < K0 || dots) ? sh[k] : 0.0;
+        __syncthreads();                     // sh is reused below (parking block) and by the caller
     }
     MAGI_STAMP(par, 3);
 

@@ -100,9 +100,17 @@ __global__ __launch_bounds__(PT_THREADS) void k_tail(DevProblem pb, DevChains ch
     __shared__ double pres[PT_POINTS * 4 * 4];
     __shared__ double predk[64 * PART_K];
     __shared__ int s_last;
+    __shared__ ChainCtl s_ctl;
+    __shared__ int s_g[2];
     if (ch.gctl->all_done) return;
     const int chain = blockIdx.y;
     const int tid = threadIdx.x;
+    // the decision state is fetched now, next to the point phase's loads, so that the workgroup that turns out to be
+    // last does not start with a round trip to memory (nobody writes it before that workgroup itself does)
+    static_assert(sizeof(ChainCtl) % 4 == 0 && sizeof(ChainCtl) / 4 <= PT_THREADS - 2, "ChainCtl prefetch");
+    if (tid < (int)(sizeof(ChainCtl) / 4)) reinterpret_cast<int*>(&s_ctl)[tid] = reinterpret_cast<const int*>(ch.ctl + chain)[tid];
+    else if (tid == PT_THREADS - 2) s_g[0] = ch.gctl->stop_k;
+    else if (tid == PT_THREADS - 1) s_g[1] = ch.gctl->epoch;
 #ifdef MAGI_TAIL_STAMPS
     const double st_entry = (double)__builtin_amdgcn_s_memrealtime();
 #endif
@@ -130,10 +138,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_tail(DevProblem pb, DevChains ch
 #ifdef MAGI_TAIL_STAMPS
     if (tid == 0) { g_stamps[8] = st_entry; g_stamps[9] = st_point; g_stamps[7] = ch.par[(size_t)chain * PAR_COUNT + 40 + 7]; g_stamps[10] = ch.par[(size_t)chain * PAR_COUNT + 40 + 10]; }
 #endif
-    ChainCtl c = ch.ctl[chain];
+    ChainCtl c = s_ctl;
     const int dim = pb.dim;
-    const int stop_k = min(ch.gctl->stop_k, cfg.total);
-    const int epoch = ch.gctl->epoch;
+    const int stop_k = min(s_g[0], cfg.total);
+    const int epoch = s_g[1];
     double* vb = ch.vec + vec_off(pb, chain, 0);
     double* par = ch.par + (size_t)chain * PAR_COUNT;
     const TailVecs v = tail_vecs(pb, vb);
