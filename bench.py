@@ -163,6 +163,19 @@ def main():
                 "kernels_us": dict(zip(["phase1", "phase2", "phase3", "reduce", "stream", "leap_reduce", "point"], [round(x * 1e3, 3) for x in phase_ms[:7]])),
                 "three_phase_gradient_eval_us": round(grad_ms * 1e3, 3)}
 
+    # measured memory-side traffic of the same kernel on the same workload, from the committed PMC passes
+    # (rocprofv3 cannot run inside the timed process; profiles/README.md has the commands)
+    try:
+        import csv
+        if N == 1024 and cpg == 1 and (band is None or 6 * band + 1 >= N):
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_bench_pmc_traffic.csv")) as fh:
+                tr = sum(float(r["bytes_per_launch_corrected"]) for r in csv.DictReader(fh) if "k_stream<1, 1>" in r["Kernel_Name"])
+            if tr > 0:
+                roofline["traffic"] = tr
+                roofline["traffic_source"] = "profiles/r01_bench_pmc_traffic.csv (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+    except (OSError, KeyError, ValueError):
+        pass
+
     # ---- CPU baseline: the numpy oracle continues the SAME chain from the GPU's current state -----------
     cpu = None
     if world == 1 and not a.no_cpu_baseline:

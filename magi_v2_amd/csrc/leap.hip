@@ -1,17 +1,9 @@
-// k_leap_*: the sampler's streaming kernel -- single-phase mat-vecs + the whole elementwise half of
-// a leapfrog, on all CUs.
-//
-// Workgroup = LEAP_RI grid indices x D waves (wave = one component d of one grid index i).  Each wave
-// streams its four operator rows (FH, FE, FE^T, FK; 16-B coalesced loads) against xc_d = X_d - mu_d
-// and f_d = drift_d(X, theta), both formed on the fly from the state vector (L1/L2 hits), for up to
-// NC chains that share every matrix byte.  After the row sums (DPP butterflies) the D waves of a
-// grid index meet in LDS and ONE lane per (grid index, chain) finishes that grid point:
-//     Ksym r = FK f - FE xc,   dL/dx_d = -1/2 (beta^-1 (2 FH xc - 2 FE^T f + J^T 2 Ksym r)_d + dt4/dx_d)
-//     p_leaf = p_half + hs g,  rho_sub += p_leaf,  checkpoint,  U-turn partial dots,
-//     speculative next leaf:  p_half' = p_leaf + hs g,  x' = x + eps p_half'   (other buffer)
-// and leaves PART_K partial sums per workgroup for the tail.  The tail therefore moves O(#WG)
-// bytes in the common case instead of ~20 state-sized vectors through one CU.
-// (reference arithmetic: magi_v2.py:308-348 and the leapfrog of TFP's NoUTurnSampler)
+// k_stream: the sampler's streaming kernel -- the four single-phase mat-vecs of a gradient
+//     hx = FH xc,  ex = FE xc,  etf = FE^T f,  kf = FK f        (xc = X - mu, f = drift(X, theta))
+// over the packed 128 x 128 operator blocks (pack.hip): the lower block triangle of the symmetric FH and FK
+// and every block of FE, each block serving a row-type and a column-type product in one pass.  The point
+// phase (leap_point.h) and the decisions (sampler.hip) follow in k_tail.
+// (reference arithmetic: magi_v2.py:308-348)
 #include "magi_internal.h"
 #include "leap_reduce.h"
 #include "leap_point.h"
