@@ -40,9 +40,15 @@ enum {
  *   SEIR3: vignette.ipynb cell 3 (S implicit; theta = beta, gamma, sigma)
  *   SEIR4: the four data columns with S explicit (data/SEIR_seed=0.csv:1)
  *   SIRW : test_magi_script.py:19-45 (theta = beta, phi, xi, chi, kappa)          */
-enum { MAGI_DRIFT_SEIR3 = 0, MAGI_DRIFT_SEIR4 = 1, MAGI_DRIFT_SIRW = 2 };
+enum { MAGI_DRIFT_SEIR3 = 0, MAGI_DRIFT_SEIR4 = 1, MAGI_DRIFT_SIRW = 2,
+       MAGI_DRIFT_USER = 3 /* only in a library specialised for a traced f_vec, see magi_user_drift_info */ };
 
 enum { MAGI_MODE_NUTS = 0, MAGI_MODE_HMC = 1 };
+
+/* Generic ODEs (callers magi_v2.py:155, 206, 335 pass an arbitrary f_vec): magi_v2_amd.drift traces the callable,
+ * emits DriftT<MAGI_DRIFT_USER> and magi_v2_amd.jit compiles this library's kernels for it.  Returns 1 and fills
+ * D, P when this library was built that way (it then accepts ONLY drift = MAGI_DRIFT_USER), else 0. */
+int magi_user_drift_info(int* D, int* P);
 
 /* ---- lifetime --------------------------------------------------------------------------- */
 

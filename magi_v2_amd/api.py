@@ -5,8 +5,9 @@ matrices, log posterior + gradient, NUTS -- runs in libmagi_hip.so on an MI355X.
 CPU implementation of that path in this package: without the library or a GPU the methods raise.
 
 What differs from the reference, deliberately:
-  * ``f_vec`` is a built-in drift name or a numpy-compatible callable that matches one
-    (host.resolve_drift); TensorFlow is not a dependency.
+  * ``f_vec`` is a built-in drift name or a numpy-compatible callable (TensorFlow is not a dependency).  A
+    callable that equals a compiled-in drift uses the hand-written kernels; any other one is traced with
+    sympy and the kernels are compiled for it (drift.py, jit.py; D <= 4, P <= 6).
   * hyper-parameters are fitted on the GPU (``magi_fit_hparams``: the reference's GP marginal
     likelihood + priors + Adam, magi_v2.py:538-691, restated -- TFP itself is not available, so this
     step is parity-unpinned); ``hparams=`` / ``hparam_iters=0`` bypass it.
@@ -19,6 +20,7 @@ from typing import Callable, Optional, Sequence, Union
 
 import numpy as np
 
+from . import drift as _drift
 from . import host
 from .engine import DRIFT_SHAPES, MagiEngine
 
@@ -80,7 +82,7 @@ class MAGI_v2:
         self.C_d_invs, self.m_ds, self.K_d_invs = None, None, None
 
         self.f_vec = f_vec
-        self.drift = host.resolve_drift(f_vec, self.D, D_thetas)
+        self.drift = _drift.resolve(f_vec, self.D, D_thetas)       # built-in, or traced + JIT-compiled (drift.py, jit.py)
         self._device = device
         self._engine: Optional[MagiEngine] = None
         self._resident = None       # fingerprint of the matrices currently on the device
@@ -89,7 +91,7 @@ class MAGI_v2:
     @property
     def engine(self) -> MagiEngine:
         if self._engine is None:
-            self._engine = MagiEngine(self._device)      # raises without libmagi_hip.so / GPU
+            self._engine = MagiEngine(self._device, drift=self.drift)      # raises without libmagi_hip.so / GPU
         return self._engine
 
     def _build(self, comps: Sequence[int], phi1s, phi2s):
@@ -124,7 +126,8 @@ class MAGI_v2:
                                        init["sigma_sqs"], init["phi1s"], init["phi2s"], init["sigma_sqs"], num_iters=num_iters)
 
     def initial_fit(self, discretization: int, verbose=False, hparams: Optional[dict] = None,
-                    theta_init_iters: int = 10000, hparam_iters: int = 1000, hparam_fit_on: str = "grid"):
+                    theta_init_iters: int = 10000, hparam_iters: int = 1000, hparam_fit_on: str = "grid",
+                    init_seed: int = 0):
         """magi_v2.py:82-277.  Hyper-parameters are fitted as in the reference (1000 Adam steps on the
         linearly interpolated discretisation grid, magi_v2.py:105-106) unless ``hparams`` carries phi1s /
         phi2s / sigma_sqs for the observed components, or ``hparam_iters=0`` keeps the reference's starting
@@ -168,9 +171,23 @@ class MAGI_v2:
         if np.all(self.observed_indicators):
             self.thetas_init = self._fit_thetas_init(theta_init_iters)
         else:
-            raise NotImplementedError(
-                "completely unobserved components (magi_v2.py:182-268) are not supported yet "
-                "(SURVEY.md section 8, rows f2/f3); set X_obs columns or fill Xhat_init/thetas_init by hand")
+            # magi_v2.py:182-268: (X_unobs, theta) jointly by finite-difference gradient matching with the observed
+            # components fixed at their smoothed values, then hyper-parameters + matrices of the unobserved components
+            self.X_interp_unobs, self.thetas_init = self._fit_unobserved(theta_init_iters, init_seed)
+            if hparams is not None and "phi1s_unobs" in hparams:
+                hpu = {"phi1s": np.asarray(hparams["phi1s_unobs"], dtype=np.float64),
+                       "phi2s": np.asarray(hparams["phi2s_unobs"], dtype=np.float64),
+                       "sigma_sqs": np.asarray(hparams["sigma_sqs_unobs"], dtype=np.float64)}
+            elif hparam_iters > 0:
+                hpu = self._fit_kernel_hparams(self.I, self.X_interp_unobs, verbose=verbose, num_iters=hparam_iters)
+            else:
+                hpu = dict(host.hparams_initial(self.X_interp_unobs))
+            self.phi1s[self.unobserved_components] = hpu["phi1s"]
+            self.phi2s[self.unobserved_components] = hpu["phi2s"]
+            self.sigma_sqs_init[self.unobserved_components] = hpu["sigma_sqs"]
+            self.Xhat_init[:, self.unobserved_components] = self.X_interp_unobs
+            self.mu_ds[self.unobserved_components] = self.X_interp_unobs.mean(axis=0)
+            self._build(self.unobserved_components, hpu["phi1s"], hpu["phi2s"])
 
         self._apply_band()
         self.Xhat_init = host.cubic_smoother(self.I, self.Xhat_init)
@@ -179,33 +196,79 @@ class MAGI_v2:
     def _fit_thetas_init(self, iters: int) -> np.ndarray:
         """magi_v2.py:133-179: Adam(lr=.01) from theta = 1 on the t2 term, *including* the
         reference's reshape (magi_v2.py:155-156 reinterprets the [N, D] drift as [D, N] instead of
-        transposing it).  The built-in drifts are linear in theta, so the objective is the
-        quadratic theta^T A theta - 2 b^T theta + c and Adam iterates on (A, b) exactly."""
+        transposing it).  Drifts that are linear in theta make the objective the quadratic
+        theta^T A theta - 2 b^T theta + c, and Adam iterates on (A, b) exactly; otherwise every step evaluates
+        the traced drift and its theta-Jacobian."""
         P, D, n = self.D_thetas, self.D, self.mag_I
-        f_np = host.NUMPY_DRIFTS[self.drift]
-        cols = []
-        for p in range(P):
-            e = np.zeros(P); e[p] = 1.0
-            cols.append(f_np(self.I, self.Xhat_init, e).reshape(D, n))          # the reshape quirk
-        zero = f_np(self.I, self.Xhat_init, np.zeros(P))
-        assert np.abs(zero).max() == 0.0, "built-in drifts are homogeneous in theta"
-        F = np.stack(cols, axis=-1)                                              # [D, n, P]
+        f_np, jac_np = self.drift.f_np, self.drift.jac_np
         Xc = (self.Xhat_init - self.mu_ds).T                                     # [D, n]
         bvec = np.einsum("dij,dj->di", self.m_ds, Xc)                            # m_d x_c
-        KF = np.einsum("dij,djp->dip", self.K_d_invs, F)
-        KTF = np.einsum("dji,djp->dip", self.K_d_invs, F)
-        A = np.einsum("dip,diq->pq", F, KF)
-        g0 = np.einsum("dip,di->p", KF + KTF, bvec)                              # gradient offset
+        Ks = np.asarray(self.K_d_invs) + np.transpose(np.asarray(self.K_d_invs), (0, 2, 1))
+        rng = np.random.default_rng(0)
+        probe = rng.uniform(0.3, 2.0, size=P)
+        cols = [f_np(self.I, self.Xhat_init, np.eye(P)[p]) for p in range(P)]
+        linear = (np.abs(f_np(self.I, self.Xhat_init, np.zeros(P))).max() == 0.0 and
+                  np.allclose(f_np(self.I, self.Xhat_init, probe), sum(probe[p] * cols[p] for p in range(P)), rtol=1e-12, atol=1e-14))
+        if linear:
+            F = np.stack([c.reshape(D, n) for c in cols], axis=-1)               # [D, n, P]   (the reshape quirk)
+            KF = np.einsum("dij,djp->dip", self.K_d_invs, F)
+            KTF = np.einsum("dji,djp->dip", self.K_d_invs, F)
+            A = np.einsum("dip,diq->pq", F, KF)
+            g0 = np.einsum("dip,di->p", KF + KTF, bvec)                          # gradient offset
+            grad_fn = lambda th: (A + A.T) @ th - g0
+        else:
+            def grad_fn(th):
+                fv = f_np(self.I, self.Xhat_init, th).reshape(D, n)              # the reshape quirk
+                _, T = jac_np(self.Xhat_init, th)                                # [n, D, P]
+                Tq = np.stack([T[:, :, p].reshape(D, n) for p in range(P)], axis=-1)   # same reshape as the drift
+                r = fv - bvec
+                return np.einsum("dip,di->p", Tq, np.einsum("dij,dj->di", Ks, r))
         theta = np.ones(P)
         m = np.zeros(P); v = np.zeros(P)
         b1, b2, lr, eps = 0.9, 0.999, 0.01, 1e-7
         for t in range(1, iters + 1):
-            grad = (A + A.T) @ theta - g0
+            grad = grad_fn(theta)
             m = b1 * m + (1 - b1) * grad
             v = b2 * v + (1 - b2) * grad * grad
             alpha = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
             theta = theta - alpha * m / (np.sqrt(v) + eps)
         return theta
+
+    def gradient_matching_loss_and_grads(self, X_obs_smoothed, X_unobs, thetas):
+        """Objective of magi_v2.py:196-216 and its gradients w.r.t. (X_unobs, thetas): the L2 mismatch between the
+        drift and the centred finite differences of the state on the interior grid points."""
+        I = self.I
+        X_full = np.concatenate([X_obs_smoothed, X_unobs], axis=1)[:, self.proper_order]
+        f = self.drift.f_np(I, X_full, thetas)
+        h2 = 2.0 * (I[1, 0] - I[0, 0])
+        r = f[1:-1] - (X_full[2:] - X_full[:-2]) / h2                            # [n-2, D]
+        J, T = self.drift.jac_np(X_full[1:-1], thetas)                           # [n-2, D, D], [n-2, D, P]
+        gX = np.zeros_like(X_full)
+        gX[1:-1] += 2.0 * np.einsum("nd,ndk->nk", r, J)
+        gX[2:] -= 2.0 * r / h2
+        gX[:-2] += 2.0 * r / h2
+        gth = 2.0 * np.einsum("nd,ndp->p", r, T)
+        return float((r ** 2).sum()), gX[:, self.unobserved_components], gth
+
+    def _fit_unobserved(self, iters: int, seed: int):
+        """magi_v2.py:182-247: Adam(lr=.01) x ``iters`` on (X_unobs, theta) jointly.  The reference draws the
+        starting X_unobs from an unseeded numpy normal (magi_v2.py:223); here the generator is seeded."""
+        Xs = host.cubic_smoother(self.I, self.X_interp_obs)
+        mu0 = self.X_interp_obs.mean()
+        sd0 = (self.X_interp_obs.std(axis=0) ** 2).mean() ** 0.5
+        rng = np.random.Generator(np.random.PCG64(seed))
+        Xu = rng.normal(loc=mu0, scale=sd0, size=(self.mag_I, self.D_unobserved))
+        th = np.ones(self.D_thetas)
+        mX, vX, mt, vt = np.zeros_like(Xu), np.zeros_like(Xu), np.zeros_like(th), np.zeros_like(th)
+        b1, b2, lr, eps = 0.9, 0.999, 0.01, 1e-7
+        for t in range(1, iters + 1):
+            _, gX, gt = self.gradient_matching_loss_and_grads(Xs, Xu, th)
+            alpha = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+            mX = b1 * mX + (1 - b1) * gX; vX = b2 * vX + (1 - b2) * gX * gX
+            mt = b1 * mt + (1 - b1) * gt; vt = b2 * vt + (1 - b2) * gt * gt
+            Xu = Xu - alpha * mX / (np.sqrt(vX) + eps)
+            th = th - alpha * mt / (np.sqrt(vt) + eps)
+        return Xu, th
 
     # ------------------------------------------------------------------------------------------
     def predict(self, num_results: int = 1000, num_burnin_steps: int = 1000, sigma_sqs_LB=None, verbose=False, *,

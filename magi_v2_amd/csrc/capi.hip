@@ -133,6 +133,17 @@ extern "C" {
 
 const char* magi_version(void) { return "magi_hip 0.1.0 gfx950"; }
 
+int magi_user_drift_info(int* D, int* P) {
+#ifdef MAGI_USER_DRIFT_HEADER
+    if (D) *D = MAGI_USER_D;
+    if (P) *P = MAGI_USER_P;
+    return 1;
+#else
+    (void)D; (void)P;
+    return 0;
+#endif
+}
+
 const char* magi_last_error(const magi_handle* h) { return h ? h->err.c_str() : g_magi_last_error.c_str(); }
 
 magi_handle* magi_create(int device_id) {
@@ -224,12 +235,19 @@ int magi_set_problem(magi_handle* h, const double* mu, const double* N_ds, const
     if (!mu || !N_ds || !LB || (n_obs > 0 && (!obs_idx || !y))) return magi_fail(h, MAGI_E_BADARG, "null pointer");
     DevProblem& pb = h->pb;
     int needD, needP;
+#ifdef MAGI_USER_DRIFT_HEADER
+    if (drift_id != MAGI_DRIFT_USER)
+        return magi_fail(h, MAGI_E_BADARG, "this library is specialised for a traced f_vec: drift id must be MAGI_DRIFT_USER");
+    needD = MAGI_USER_D; needP = MAGI_USER_P;
+#else
     switch (drift_id) {
     case MAGI_DRIFT_SEIR3: needD = 3; needP = 3; break;
     case MAGI_DRIFT_SEIR4: needD = 4; needP = 3; break;
     case MAGI_DRIFT_SIRW: needD = 4; needP = 5; break;
+    case MAGI_DRIFT_USER: return magi_fail(h, MAGI_E_BADARG, "no user drift compiled into this library (magi_v2_amd.jit builds one)");
     default: return magi_fail(h, MAGI_E_BADARG, "unknown drift id");
     }
+#endif
     if (pb.D != needD || P != needP)
         return magi_fail(h, MAGI_E_BADARG, "drift expects D=" + std::to_string(needD) + ", P=" + std::to_string(needP));
     (void)hipSetDevice(h->device);

@@ -238,11 +238,10 @@ int launch_stream_nd(magi_handle* h, int n_chains, hipStream_t s) {
 
 template <int NC>
 int launch_stream_nc(magi_handle* h, int n_chains, hipStream_t s) {
-    switch (h->pb.drift) {
-    case MAGI_DRIFT_SEIR3: return launch_stream_nd<NC, MAGI_DRIFT_SEIR3>(h, n_chains, s);
-    case MAGI_DRIFT_SEIR4: return launch_stream_nd<NC, MAGI_DRIFT_SEIR4>(h, n_chains, s);
-    default: return launch_stream_nd<NC, MAGI_DRIFT_SIRW>(h, n_chains, s);
-    }
+#define MAGI_CALL(DR) return launch_stream_nd<NC, DR>(h, n_chains, s)
+    MAGI_DRIFT_DISPATCH(h->pb.drift, MAGI_CALL);
+#undef MAGI_CALL
+    return MAGI_OK;
 }
 
 }  // namespace
@@ -258,11 +257,9 @@ int magi_launch_stream(magi_handle* h, int n_chains, hipStream_t s) {
 int magi_launch_point(magi_handle* h, int n_chains, hipStream_t s) {
     const DevProblem& pb = h->pb;
     const dim3 g(magi_leap_wgs(pb), n_chains), b(PT_THREADS);
-    switch (pb.drift) {
-    case MAGI_DRIFT_SEIR3: hipLaunchKernelGGL(k_point<MAGI_DRIFT_SEIR3>, g, b, 0, s, pb, h->ch); break;
-    case MAGI_DRIFT_SEIR4: hipLaunchKernelGGL(k_point<MAGI_DRIFT_SEIR4>, g, b, 0, s, pb, h->ch); break;
-    default: hipLaunchKernelGGL(k_point<MAGI_DRIFT_SIRW>, g, b, 0, s, pb, h->ch); break;
-    }
+#define MAGI_CALL(DR) hipLaunchKernelGGL(k_point<DR>, g, b, 0, s, pb, h->ch)
+    MAGI_DRIFT_DISPATCH(pb.drift, MAGI_CALL);
+#undef MAGI_CALL
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("point launch: ") + hipGetErrorString(e));
     return MAGI_OK;
@@ -283,11 +280,9 @@ int magi_launch_plan_eval(magi_handle* h, int n_chains, hipStream_t s) {
 
 int magi_launch_leap_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s) {
     const dim3 g(n_chains), b(MAGI_TAIL_THREADS);
-    switch (h->pb.drift) {
-    case MAGI_DRIFT_SEIR3: hipLaunchKernelGGL(k_leap_finalize<MAGI_DRIFT_SEIR3>, g, b, 0, s, h->pb, h->ch, d_out); break;
-    case MAGI_DRIFT_SEIR4: hipLaunchKernelGGL(k_leap_finalize<MAGI_DRIFT_SEIR4>, g, b, 0, s, h->pb, h->ch, d_out); break;
-    default: hipLaunchKernelGGL(k_leap_finalize<MAGI_DRIFT_SIRW>, g, b, 0, s, h->pb, h->ch, d_out); break;
-    }
+#define MAGI_CALL(DR) hipLaunchKernelGGL(k_leap_finalize<DR>, g, b, 0, s, h->pb, h->ch, d_out)
+    MAGI_DRIFT_DISPATCH(h->pb.drift, MAGI_CALL);
+#undef MAGI_CALL
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("leap_finalize launch: ") + hipGetErrorString(e));
     return MAGI_OK;

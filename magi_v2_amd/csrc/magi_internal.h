@@ -283,9 +283,28 @@ __device__ inline void compute_par_entry(const DevProblem& pb, int j, double pre
 
 // ------------------------------------------------------------------------------------------
 // Drifts.  x[] = state at one grid point, th[] = softplus'ed parameters.
+// A library built with -DMAGI_USER_DRIFT_HEADER="<file>" carries ONE drift traced from the caller's f_vec
+// (magi_v2_amd/drift.py, jit.py) and instantiates the sampler's kernels for it alone.
 // ------------------------------------------------------------------------------------------
+template <int DRIFT> struct DriftT;
+#ifdef MAGI_USER_DRIFT_HEADER
+#include MAGI_USER_DRIFT_HEADER
+#define MAGI_DRIFT_DISPATCH(drift, CALL) do { CALL(MAGI_DRIFT_USER); } while (0)
+#else
+#define MAGI_DRIFT_DISPATCH(drift, CALL)                         \
+    do {                                                         \
+        switch (drift) {                                         \
+        case MAGI_DRIFT_SEIR3: CALL(MAGI_DRIFT_SEIR3); break;    \
+        case MAGI_DRIFT_SEIR4: CALL(MAGI_DRIFT_SEIR4); break;    \
+        default: CALL(MAGI_DRIFT_SIRW); break;                   \
+        }                                                        \
+    } while (0)
+#endif
 __device__ __forceinline__ double drift_f(int drift, int d, const double* x, const double* th) {
     switch (drift) {
+#ifdef MAGI_USER_DRIFT_HEADER
+    case MAGI_DRIFT_USER: return user_drift_f(d, x, th);
+#endif
     case MAGI_DRIFT_SEIR3: {   // vignette.ipynb cell 3
         double E = x[0], I = x[1], R = x[2], S = 1.0 - ((E + I) + R);
         if (d == 0) return (th[0] * S * I) - (th[2] * E);
@@ -312,6 +331,13 @@ __device__ __forceinline__ double drift_f(int drift, int d, const double* x, con
 // sum_d' g[d'] * d f_d' / d x_d   (column d of the Jacobian contracted with g)
 __device__ __forceinline__ double drift_jt_g(int drift, int d, const double* x, const double* th, const double* g) {
     switch (drift) {
+#ifdef MAGI_USER_DRIFT_HEADER
+    case MAGI_DRIFT_USER: {
+        double c[MAGI_MAX_D] = {0.0, 0.0, 0.0, 0.0};
+        user_drift_jt(x, th, g, c, nullptr);
+        return d == 0 ? c[0] : d == 1 ? c[1] : d == 2 ? c[2] : c[3];
+    }
+#endif
     case MAGI_DRIFT_SEIR3: {
         double E = x[0], I = x[1], R = x[2], S = 1.0 - ((E + I) + R);
         double b = th[0], gm = th[1], s = th[2];
@@ -343,6 +369,14 @@ __device__ __forceinline__ void drift_tt_g_acc(int drift, const double (&x)[MAGI
                                                const double (&g)[MAGI_MAX_D], double (&out)[MAGI_MAX_P]) {
     // every case fills the same five scalars so the accumulation below keeps static indices
     double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0, o4 = 0.0;
+#ifdef MAGI_USER_DRIFT_HEADER
+    if (drift == MAGI_DRIFT_USER) {
+        double t[MAGI_MAX_P] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        user_drift_jt(x, th, g, nullptr, t);
+        out[0] += t[0]; out[1] += t[1]; out[2] += t[2]; out[3] += t[3]; out[4] += t[4]; out[5] += t[5];
+        return;
+    }
+#endif
     switch (drift) {
     case MAGI_DRIFT_SEIR3: {
         const double E = x[0], I = x[1], R = x[2], S = 1.0 - ((E + I) + R);
@@ -374,8 +408,6 @@ __device__ __forceinline__ void drift_tt_g_acc(int drift, const double (&x)[MAGI
 // ------------------------------------------------------------------------------------------
 // Compile-time drifts for the sampler's kernels (D, P known -> no guards, no switch, small code)
 // ------------------------------------------------------------------------------------------
-template <int DRIFT> struct DriftT;
-
 template <> struct DriftT<MAGI_DRIFT_SEIR3> {
     static constexpr int D = 3, P = 3;
     static __device__ __forceinline__ void f(const double (&x)[3], const double (&th)[3], double (&o)[3]) {

@@ -436,11 +436,9 @@ __global__ void k_init_chains(DevChains ch, SamplerCfgDev cfg, const long long* 
 
 int magi_launch_tail(magi_handle* h, int n_chains, hipStream_t s) {
     const dim3 g(h->ch.n_wg, n_chains), b(PT_THREADS);
-    switch (h->pb.drift) {
-    case MAGI_DRIFT_SEIR3: hipLaunchKernelGGL(k_tail<MAGI_DRIFT_SEIR3>, g, b, 0, s, h->pb, h->ch, h->cfg); break;
-    case MAGI_DRIFT_SEIR4: hipLaunchKernelGGL(k_tail<MAGI_DRIFT_SEIR4>, g, b, 0, s, h->pb, h->ch, h->cfg); break;
-    default: hipLaunchKernelGGL(k_tail<MAGI_DRIFT_SIRW>, g, b, 0, s, h->pb, h->ch, h->cfg); break;
-    }
+#define MAGI_CALL(DR) hipLaunchKernelGGL(k_tail<DR>, g, b, 0, s, h->pb, h->ch, h->cfg)
+    MAGI_DRIFT_DISPATCH(h->pb.drift, MAGI_CALL);
+#undef MAGI_CALL
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("tail launch: ") + hipGetErrorString(e));
     return MAGI_OK;

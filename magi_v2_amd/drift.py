@@ -1,0 +1,246 @@
+"""Drift front-end: turn the reference's ``f_vec`` argument (magi_v2.py:33, 73; called at :155, :206, :335)
+into what the engine needs.
+
+The reference traces an arbitrary Python callable ``f_vec(t[N,1], X[N,D], theta[P]) -> [N,D]`` into XLA and
+lets autodiff produce the Jacobians.  Here the callable is traced once with sympy symbols in numpy object
+arrays (slicing, arithmetic, ``np.sum / np.concatenate / np.reshape / np.stack`` and sympy functions all work
+on those), differentiated symbolically, and emitted twice:
+
+* vectorised numpy evaluators of f, df/dx and df/dtheta (host-side initialisation: theta / unobserved-component
+  fits, magi_v2.py:133-268), and
+* a C++ header with ``DriftT<MAGI_DRIFT_USER>`` and the runtime-switch functions of ``magi_internal.h``; the
+  sampler's kernels are compiled for it by ``magi_v2_amd.jit`` (hipcc, gfx950) into a specialised library.
+
+Callables that agree with a compiled-in drift (SEIR-3 of vignette.ipynb cell 3, SEIR-4, SIRW of
+test_magi_script.py:19-45) use the hand-written kernels of the base library.  Limits: D <= 4, P <= 6 (the
+per-workgroup partial-sum layout), autonomous systems (``t`` may be passed but must not be used), drifts
+expressible with elementwise arithmetic and sympy-known functions."""
+from __future__ import annotations
+
+import hashlib
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+
+MAX_D, MAX_P = 4, 6
+BUILTIN_IDS = {"seir3": 0, "seir4": 1, "sirw": 2}
+USER_ID = 3
+
+
+def _sympy():
+    try:
+        import sympy
+    except ImportError as exc:   # pragma: no cover - sympy ships with the image
+        raise NotImplementedError("generic drifts need sympy for tracing; use a built-in drift name") from exc
+    return sympy
+
+
+@dataclass
+class Drift:
+    """A drift the engine can run: name, shape, device id, numpy evaluators and (user drifts) C++ source."""
+    name: str
+    D: int
+    P: int
+    device_id: int
+    f_np: Callable            # (t, X[N,D], th[P]) -> [N,D]
+    jac_np: Callable          # (X[N,D], th[P]) -> J[N,D,D] (d f_d / d x_k), T[N,D,P] (d f_d / d theta_p)
+    header: Optional[str] = None
+    exprs: List = field(default_factory=list, repr=False)
+
+    @property
+    def is_builtin(self) -> bool:
+        return self.device_id != USER_ID
+
+
+def _trace(f_vec: Callable, D: int, P: int):
+    sp = _sympy()
+    xs = sp.symbols(f"x0:{D}", real=True)
+    ths = sp.symbols(f"th0:{P}", real=True)
+    tsym = sp.Symbol("t_magi", real=True)
+    X = np.array([list(xs)], dtype=object)
+    th = np.array(list(ths), dtype=object)
+    t = np.array([[tsym]], dtype=object)
+    try:
+        out = f_vec(t, X, th)
+    except Exception as exc:
+        raise NotImplementedError(
+            "f_vec could not be traced: write it with numpy-compatible operations (slicing, + - * /, np.sum, "
+            "np.concatenate, np.reshape, np.stack, sympy functions) -- " + repr(exc)) from exc
+    out = np.asarray(out, dtype=object)
+    if out.shape != (1, D):
+        raise ValueError(f"f_vec must return an array of shape [N, D]; traced shape {out.shape} for D = {D}")
+    exprs = [sp.sympify(out[0, d]) for d in range(D)]
+    for e in exprs:
+        if e.has(tsym):
+            raise NotImplementedError("non-autonomous drifts (explicit use of t) are not supported")
+        extra = e.free_symbols - set(xs) - set(ths)
+        if extra:
+            raise ValueError(f"f_vec produced unknown symbols {extra}")
+    return sp, xs, ths, exprs
+
+
+def _c_printer():
+    sp = _sympy()
+    from sympy.printing.c import C99CodePrinter
+
+    class Printer(C99CodePrinter):
+        def _print_Pow(self, expr):          # small integer powers as products (fp64 pow() is a long sequence)
+            b, e = expr.as_base_exp()
+            if e.is_Integer and 2 <= int(e) <= 4:
+                s = self.parenthesize(b, 1000)
+                return "(" + "*".join([s] * int(e)) + ")"
+            if e.is_Integer and -4 <= int(e) <= -1:
+                s = self.parenthesize(b, 1000)
+                return "(1.0/(" + "*".join([s] * (-int(e))) + "))"
+            return super()._print_Pow(expr)
+
+        def _print_Rational(self, expr):
+            return f"({int(expr.p)}.0/{int(expr.q)}.0)"
+
+        def _print_Integer(self, expr):
+            return f"{int(expr)}.0"
+
+    return Printer()
+
+
+def _emit_block(sp, printer, outputs: List[Tuple[str, object]], subs: dict, indent: str = "        ") -> str:
+    """C statements computing ``lhs = expr`` for every output, with common subexpressions hoisted."""
+    exprs = [e.xreplace(subs) for _, e in outputs]
+    temps, reduced = sp.cse(exprs, symbols=sp.numbered_symbols("q_"), optimizations="basic")
+    lines = [f"{indent}const double {printer.doprint(s)} = {printer.doprint(v)};" for s, v in temps]
+    for (lhs, _), r in zip(outputs, reduced):
+        lines.append(f"{indent}{lhs} {printer.doprint(r)};")
+    return "\n".join(lines)
+
+
+def _header(sp, xs, ths, exprs, D: int, P: int, tag: str) -> str:
+    pr = _c_printer()
+    xa = {xs[k]: sp.Symbol(f"x[{k}]") for k in range(D)}
+    ta = {ths[k]: sp.Symbol(f"th[{k}]") for k in range(P)}
+    ga = [sp.Symbol(f"g[{d}]") for d in range(D)]
+    subs = {**xa, **ta}
+    J = [[sp.diff(exprs[d], xs[k]) for k in range(D)] for d in range(D)]
+    T = [[sp.diff(exprs[d], ths[p]) for p in range(P)] for d in range(D)]
+    cJ = [sum(ga[d] * J[d][k] for d in range(D)) for k in range(D)]          # (J^T g)_k
+    cT = [sum(ga[d] * T[d][p] for d in range(D)) for p in range(P)]          # (T^T g)_p
+    f_body = _emit_block(sp, pr, [(f"o[{d}] =", exprs[d]) for d in range(D)], subs)
+    jt_body = _emit_block(sp, pr, [(f"c[{k}] =", cJ[k]) for k in range(D)] + [(f"t[{p}] +=", cT[p]) for p in range(P)], subs)
+    sel = " : ".join([f"d == {d} ? o[{d}]" for d in range(D - 1)] + [f"o[{D - 1}]"]) if D > 1 else "o[0]"
+    selc = " : ".join([f"d == {d} ? c[{d}]" for d in range(D - 1)] + [f"c[{D - 1}]"]) if D > 1 else "c[0]"
+    return f"""// generated by magi_v2_amd.drift ({tag}) -- do not edit
+#pragma once
+#define MAGI_USER_D {D}
+#define MAGI_USER_P {P}
+template <> struct DriftT<MAGI_DRIFT_USER> {{
+    static constexpr int D = {D}, P = {P};
+    static __device__ __forceinline__ void f(const double (&x)[{D}], const double (&th)[{P}], double (&o)[{D}]) {{
+{f_body}
+    }}
+    static __device__ __forceinline__ double f1(int d, const double (&x)[{D}], const double (&th)[{P}]) {{
+        double o[{D}];
+        f(x, th, o);
+        return {sel};
+    }}
+    // c[k] = sum_d g[d] df_d/dx_k ; t[p] += sum_d g[d] df_d/dtheta_p
+    static __device__ __forceinline__ void jt(const double (&x)[{D}], const double (&th)[{P}], const double (&g)[{D}], double (&c)[{D}], double (&t)[{P}]) {{
+{jt_body}
+    }}
+}};
+// runtime-switch entry points of the reference-order (three-phase) kernels
+__device__ __forceinline__ double user_drift_f(int d, const double* xp, const double* thp) {{
+    double x[{D}], th[{P}];
+    for (int k = 0; k < {D}; ++k) x[k] = xp[k];
+    for (int k = 0; k < {P}; ++k) th[k] = thp[k];
+    return DriftT<MAGI_DRIFT_USER>::f1(d, x, th);
+}}
+__device__ __forceinline__ void user_drift_jt(const double* xp, const double* thp, const double* gp, double* cout, double* tacc) {{
+    double x[{D}], th[{P}], g[{D}], c[{D}], t[{P}];
+    for (int k = 0; k < {D}; ++k) {{ x[k] = xp[k]; g[k] = gp[k]; }}
+    for (int k = 0; k < {P}; ++k) {{ th[k] = thp[k]; t[k] = 0.0; }}
+    DriftT<MAGI_DRIFT_USER>::jt(x, th, g, c, t);
+    if (cout) for (int k = 0; k < {D}; ++k) cout[k] = c[k];
+    if (tacc) for (int k = 0; k < {P}; ++k) tacc[k] += t[k];
+}}
+"""
+
+
+def _numpy_evaluators(sp, xs, ths, exprs, D: int, P: int):
+    J = [[sp.diff(exprs[d], xs[k]) for k in range(D)] for d in range(D)]
+    T = [[sp.diff(exprs[d], ths[p]) for p in range(P)] for d in range(D)]
+    args = list(xs) + list(ths)
+    f_l = sp.lambdify(args, exprs, modules="numpy", cse=True)
+    j_l = sp.lambdify(args, [J[d][k] for d in range(D) for k in range(D)], modules="numpy", cse=True)
+    t_l = sp.lambdify(args, [T[d][p] for d in range(D) for p in range(P)], modules="numpy", cse=True)
+
+    def cols(X, th):
+        X = np.asarray(X, dtype=np.float64)
+        return [X[:, k] for k in range(D)] + [float(v) for v in np.asarray(th, dtype=np.float64)]
+
+    def f_np(t, X, th):
+        a = cols(X, th)
+        n = np.asarray(X).shape[0]
+        return np.stack([np.broadcast_to(np.asarray(v, dtype=np.float64), (n,)) for v in f_l(*a)], axis=1)
+
+    def jac_np(X, th):
+        a = cols(X, th)
+        n = np.asarray(X).shape[0]
+        Jv = np.stack([np.broadcast_to(np.asarray(v, dtype=np.float64), (n,)) for v in j_l(*a)], axis=1).reshape(n, D, D)
+        Tv = np.stack([np.broadcast_to(np.asarray(v, dtype=np.float64), (n,)) for v in t_l(*a)], axis=1).reshape(n, D, P)
+        return Jv, Tv
+
+    return f_np, jac_np
+
+
+def trace_drift(f_vec: Callable, D: int, P: int, name: Optional[str] = None) -> Drift:
+    """Trace a numpy-compatible ``f_vec`` into a user :class:`Drift` (device id MAGI_DRIFT_USER)."""
+    if not (1 <= D <= MAX_D and 1 <= P <= MAX_P):
+        raise NotImplementedError(f"generic drifts support D <= {MAX_D} components and P <= {MAX_P} parameters (got {D}, {P})")
+    sp, xs, ths, exprs = _trace(f_vec, D, P)
+    key = hashlib.sha256(("|".join(sp.srepr(e) for e in exprs) + f"|{D}|{P}").encode()).hexdigest()[:16]
+    tag = name or f"user_{key}"
+    f_np, jac_np = _numpy_evaluators(sp, xs, ths, exprs, D, P)
+    return Drift(name=tag, D=D, P=P, device_id=USER_ID, f_np=f_np, jac_np=jac_np,
+                 header=_header(sp, xs, ths, exprs, D, P, tag), exprs=exprs)
+
+
+def builtin_drift(name: str) -> Drift:
+    """A compiled-in drift; its numpy Jacobians come from tracing the host restatement (host.NUMPY_DRIFTS)."""
+    from . import host
+    from .engine import DRIFT_SHAPES
+    D, P = DRIFT_SHAPES[name]
+    sp, xs, ths, exprs = _trace(host.NUMPY_DRIFTS[name], D, P)
+    _, jac_np = _numpy_evaluators(sp, xs, ths, exprs, D, P)
+    return Drift(name=name, D=D, P=P, device_id=BUILTIN_IDS[name], f_np=host.NUMPY_DRIFTS[name], jac_np=jac_np, exprs=exprs)
+
+
+def resolve(f_vec, D: int, P: int) -> Drift:
+    """magi_v2.py:33: accept a built-in name, a callable that equals a built-in, or any traceable callable."""
+    from . import host
+    from .engine import DRIFT_SHAPES
+    if isinstance(f_vec, Drift):
+        return f_vec
+    if isinstance(f_vec, str):
+        if f_vec not in DRIFT_SHAPES:
+            raise ValueError(f"unknown drift {f_vec!r}; built-ins: {sorted(DRIFT_SHAPES)}")
+        if DRIFT_SHAPES[f_vec] != (D, P):
+            raise ValueError(f"drift {f_vec!r} needs (D, P) = {DRIFT_SHAPES[f_vec]}, got {(D, P)}")
+        return builtin_drift(f_vec)
+    if not callable(f_vec):
+        raise TypeError("f_vec must be a drift name or a callable")
+    rng = np.random.default_rng(0)
+    X = rng.uniform(0.05, 0.6, size=(7, D))
+    th = rng.uniform(0.2, 2.0, size=(P,))
+    t = np.linspace(0, 1, 7).reshape(-1, 1)
+    try:
+        got = np.asarray(f_vec(t, X, th), dtype=np.float64)
+    except Exception as exc:   # e.g. a TensorFlow-only function
+        raise NotImplementedError(
+            "f_vec could not be evaluated on numpy arrays; pass a built-in drift name "
+            f"({sorted(DRIFT_SHAPES)}) or a numpy-compatible callable") from exc
+    if got.shape != (7, D):
+        raise ValueError(f"f_vec must return [N, D]; got {got.shape}")
+    for name, (d, p) in DRIFT_SHAPES.items():
+        if (d, p) == (D, P) and np.allclose(got, host.NUMPY_DRIFTS[name](t, X, th), rtol=1e-12, atol=1e-14):
+            return builtin_drift(name)
+    return trace_drift(f_vec, D, P)

@@ -42,6 +42,7 @@ _SYMBOLS = {
     "magi_destroy": (None, [C.c_void_p]),
     "magi_last_error": (C.c_char_p, [C.c_void_p]),
     "magi_version": (C.c_char_p, []),
+    "magi_user_drift_info": (C.c_int, [_ip, _ip]),
     "magi_build_matrices": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, _dp, _dp, _dp]),
     "magi_matern_blocks": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp]),
     "magi_fit_hparams": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_double,
@@ -64,15 +65,15 @@ _SYMBOLS = {
     "magi_build_profile": (C.c_int, [C.c_void_p, _dp, _dp, _lp]),
 }
 
-_lib = None
+_libs = {}
 
 
 def load_library(path: Optional[str] = None):
-    """dlopen libmagi_hip.so and declare every symbol of include/magi_hip.h.  Raises if absent."""
-    global _lib
-    if _lib is not None and path is None:
-        return _lib
-    p = path or os.environ.get("MAGI_HIP_LIB") or LIB_PATH      # MAGI_HIP_LIB: A/B builds in one session
+    """dlopen libmagi_hip.so (or a drift-specialised build of it, magi_v2_amd.jit) and declare every symbol of
+    include/magi_hip.h.  Raises if absent."""
+    p = os.path.abspath(path or os.environ.get("MAGI_HIP_LIB") or LIB_PATH)      # MAGI_HIP_LIB: A/B builds in one session
+    if p in _libs:
+        return _libs[p]
     if not os.path.exists(p):
         raise ImportError(f"{p} not found: build it with `python -m magi_v2_amd.build` (hipcc, gfx950); "
                           "magi_v2_amd has no CPU fallback")
@@ -81,8 +82,7 @@ def load_library(path: Optional[str] = None):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if path is None:
-        _lib = lib
+    _libs[p] = lib
     return lib
 
 
@@ -118,8 +118,16 @@ class SamplerDiag:
 class MagiEngine:
     """One handle = one GPU.  Not thread-safe; different engines may be used from different threads."""
 
-    def __init__(self, device_id: int = 0):
-        self._lib = load_library()
+    def __init__(self, device_id: int = 0, drift=None):
+        """``drift``: a magi_v2_amd.drift.Drift traced from a user f_vec -> the engine runs the library that
+        magi_v2_amd.jit compiles for it; None / a built-in -> the base library."""
+        self.user_drift = None
+        if drift is not None and not getattr(drift, "is_builtin", True):
+            from . import jit
+            self._lib = load_library(jit.library_for(drift))
+            self.user_drift = drift
+        else:
+            self._lib = load_library()
         self._h = self._lib.magi_create(int(device_id))
         if not self._h:
             raise MagiHipError(-2, self._lib.magi_last_error(None).decode())
@@ -193,14 +201,20 @@ class MagiEngine:
         self.N, self.D = N, D
 
     # -- problem --------------------------------------------------------------------------------
-    def set_problem(self, mu, N_ds, obs_idx, y, beta, LB, drift: str):
+    def set_problem(self, mu, N_ds, obs_idx, y, beta, LB, drift):
+        """``drift``: built-in name, or the Drift this engine was created for."""
         D = self.D
-        P = DRIFT_SHAPES[drift][1]
+        if not isinstance(drift, str):
+            if self.user_drift is None and not drift.is_builtin:
+                raise ValueError("engine was not created for this user drift: MagiEngine(device, drift=...)")
+            P, drift_id = drift.P, drift.device_id
+        else:
+            P, drift_id = DRIFT_SHAPES[drift][1], DRIFT_IDS[drift]
         mu, N_ds, LB = _f64(mu, (D,)), _f64(N_ds, (D,)), _f64(LB, (D,))
         obs_idx = np.ascontiguousarray(obs_idx, dtype=np.int64)
         y = _f64(y, obs_idx.shape)
         self._check(self._lib.magi_set_problem(self._h, _ptr(mu), _ptr(N_ds), obs_idx.ctypes.data_as(_lp), _ptr(y),
-                                               obs_idx.shape[0], float(beta), _ptr(LB), DRIFT_IDS[drift], P))
+                                               obs_idx.shape[0], float(beta), _ptr(LB), drift_id, P))
         self.P = P
 
     def _states(self, X, sig_pre, th_pre):

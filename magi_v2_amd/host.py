@@ -142,37 +142,10 @@ NUMPY_DRIFTS: Dict[str, Callable] = {"seir3": _np_seir3, "seir4": _np_seir4, "si
 
 
 def resolve_drift(f_vec, D: int, P: int) -> str:
-    """Map the reference's ``f_vec`` argument (magi_v2.py:33, 73) onto a compiled-in device drift.
-
-    Accepted: the name of a built-in ("seir3", "seir4", "sirw"), or a callable
-    f(t[N,1], X[N,D], theta[P]) -> [N,D] written against numpy-compatible arrays that agrees
-    numerically with a built-in of matching shape (the vignette's SEIR function and
-    test_magi_script.py's SIRW function do once their tf.* calls are spelled with numpy).
-    Arbitrary callables need the tracing front-end of SURVEY 8 row f4 and are rejected loudly."""
-    from .engine import DRIFT_SHAPES
-    if isinstance(f_vec, str):
-        if f_vec not in DRIFT_SHAPES:
-            raise ValueError(f"unknown drift {f_vec!r}; built-ins: {sorted(DRIFT_SHAPES)}")
-        if DRIFT_SHAPES[f_vec] != (D, P):
-            raise ValueError(f"drift {f_vec!r} needs (D, P) = {DRIFT_SHAPES[f_vec]}, got {(D, P)}")
-        return f_vec
-    if not callable(f_vec):
-        raise TypeError("f_vec must be a drift name or a callable")
-    rng = np.random.default_rng(0)
-    X = rng.uniform(0.05, 0.6, size=(7, D))
-    th = rng.uniform(0.2, 2.0, size=(P,))
-    t = np.linspace(0, 1, 7).reshape(-1, 1)
-    try:
-        got = np.asarray(f_vec(t, X, th), dtype=np.float64)
-    except Exception as exc:   # e.g. a TensorFlow-only function
-        raise NotImplementedError(
-            "f_vec could not be evaluated on numpy arrays; pass a built-in drift name "
-            f"({sorted(DRIFT_SHAPES)}) or a numpy-compatible callable matching one") from exc
-    for name, (d, p) in DRIFT_SHAPES.items():
-        if (d, p) == (D, P) and got.shape == (7, D) and np.allclose(got, NUMPY_DRIFTS[name](t, X, th), rtol=1e-12, atol=1e-14):
-            return name
-    raise NotImplementedError("f_vec does not match a compiled-in drift (seir3 / seir4 / sirw); "
-                              "generic ODEs are not supported yet (SURVEY.md section 8, row f4)")
+    """Name of the drift ``f_vec`` resolves to (magi_v2.py:33, 73): a compiled-in one ("seir3", "seir4", "sirw")
+    when the callable agrees with it numerically, else the name of the traced user drift (drift.resolve)."""
+    from . import drift
+    return drift.resolve(f_vec, D, P).name
 
 
 # --------------------------------------------------------------------------------------------

@@ -126,6 +126,15 @@ def hparams_initial(X_filled: np.ndarray) -> Dict[str, np.ndarray]:
 # --------------------------------------------------------------------------------------
 
 
+def gradient_matching_loss(I, X_obs_smoothed, X_unobs, thetas, proper_order, drift):
+    """magi_v2.py:196-216: objective of the joint (X_unobs, theta) initialisation of completely unobserved
+    components -- squared mismatch between the drift and centred finite differences on the interior grid."""
+    X_full = np.concatenate([X_obs_smoothed, X_unobs], axis=1)[:, proper_order]          # tf.gather(..., axis=1)
+    f_vals = DRIFTS[drift][0](X_full, thetas)[0]
+    f_diff = (X_full[2:, :] - X_full[:-2, :]) / (2 * (I[1, 0] - I[0, 0]))
+    return float(np.sum((f_vals[1:-1] - f_diff) ** 2))
+
+
 def gp_marginal_and_grad(I, x, mu, phi1, phi2, sig2, nu=2.01, jitter=1e-6):
     """log N(x; mu, S) and d/d(phi1, phi2, sig2), S = Kappa(phi1, phi2) + (sig2 + jitter) I."""
     I = np.asarray(I, dtype=np.float64).reshape(-1)
