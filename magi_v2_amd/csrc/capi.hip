@@ -31,7 +31,7 @@ void free_matrices(magi_handle* h) {
 
 void free_chains(magi_handle* h) {
     DevChains& c = h->ch;
-    free_dev(c.vec); free_dev(c.ctl); free_dev(c.par); free_dev(c.plan); free_dev(c.part); free_dev(c.tpart); free_dev(c.ticket); free_dev(c.gctl); free_dev(c.samples);
+    free_dev(c.vec); free_dev(c.ctl); free_dev(c.par); free_dev(c.plan); free_dev(c.part); free_dev(c.tpart); free_dev(c.gctl); free_dev(c.samples);
     free_dev(c.d_step_size); free_dev(c.d_lar); free_dev(c.d_target); free_dev(c.d_energy); free_dev(c.d_beta);
     free_dev(c.d_leapfrogs); free_dev(c.d_depth); free_dev(c.d_flags);
     free_dev(h->d_chain_ids); free_dev(h->d_fin);
@@ -80,9 +80,9 @@ int build_graph(magi_handle* h) {
     drop_graph(h);
     MAGI_HIP_CHECK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     int rc = MAGI_OK;
-    for (int s = 0; s < kGraphSlots && rc == MAGI_OK; ++s) {
-        rc = magi_launch_stream(h, h->n_chains, h->stream);
-        if (rc == MAGI_OK) rc = magi_launch_tail(h, h->n_chains, h->stream);
+    for (int s = 0; s < kGraphSlots && rc == MAGI_OK; ++s) {          // kGraphSlots is even: a graph starts at slot parity 0
+        rc = magi_launch_stream(h, h->n_chains, s & 1, true, h->stream);
+        if (rc == MAGI_OK) rc = magi_launch_point(h, h->n_chains, s & 1, h->stream);
     }
     hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
     if (rc != MAGI_OK) return rc;
@@ -107,13 +107,11 @@ int magi_ensure_chains(magi_handle* h, int n) {
         MAGI_HIP_CHECK(h, hipMemset(h->ch.ctl, 0, sizeof(ChainCtl) * n));
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.par, sizeof(double) * PAR_COUNT * n));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.par, 0, sizeof(double) * PAR_COUNT * n));
-        MAGI_HIP_CHECK(h, hipMalloc(&h->ch.plan, sizeof(LeafPlan) * n));
-        MAGI_HIP_CHECK(h, hipMemset(h->ch.plan, 0, sizeof(LeafPlan) * n));
+        MAGI_HIP_CHECK(h, hipMalloc(&h->ch.plan, sizeof(LeafPlan) * 2 * n));
+        MAGI_HIP_CHECK(h, hipMemset(h->ch.plan, 0, sizeof(LeafPlan) * 2 * n));
         h->ch.n_wg = magi_leap_wgs(h->pb);
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.part, sizeof(double) * PART_K * h->ch.n_wg * n));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.part, 0, sizeof(double) * PART_K * h->ch.n_wg * n));
-        MAGI_HIP_CHECK(h, hipMalloc(&h->ch.ticket, sizeof(int) * n));
-        MAGI_HIP_CHECK(h, hipMemset(h->ch.ticket, 0, sizeof(int) * n));
         const size_t tpn = (size_t)n * 4 * h->pb.D * h->pb.nb * h->pb.Np;
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.tpart, sizeof(double) * tpn));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.tpart, 0, sizeof(double) * tpn));     // slots outside the block band stay zero
@@ -294,7 +292,8 @@ static int logpost_grad_impl(magi_handle* h, bool fused, int n_chains, const dou
     if ((rc = magi_launch_prepare(h, n_chains, h->stream))) return rc;
     if (fused) {
         if ((rc = magi_launch_plan_eval(h, n_chains, h->stream))) return rc;
-        if ((rc = magi_launch_leap(h, n_chains, h->stream))) return rc;
+        if ((rc = magi_launch_stream(h, n_chains, 0, false, h->stream))) return rc;
+        if ((rc = magi_launch_point(h, n_chains, 0, h->stream))) return rc;
         if ((rc = magi_launch_leap_finalize(h, n_chains, h->d_fin, h->stream))) return rc;
     } else {
         if ((rc = magi_launch_gradient(h, n_chains, h->stream))) return rc;
@@ -402,11 +401,13 @@ int magi_sampler_init(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains,
     for (int i = 0; i < n_chains; ++i) ids[i] = chain_ids ? (long long)chain_ids[i] : (long long)i;
     MAGI_HIP_CHECK(h, hipMemcpy(h->d_chain_ids, ids.data(), sizeof(long long) * n_chains, hipMemcpyHostToDevice));
     if ((rc = magi_launch_init_chains(h, h->d_chain_ids, h->stream))) return rc;
-    MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.ticket, 0, sizeof(int) * n_chains, h->stream));
-    // bootstrap_results: one gradient at the initial state (the tail stores it as the proposal)
+    // bootstrap_results: one gradient at the initial state.  Slot 0 evaluates it, the decisions riding in slot 1's
+    // stream store it as the proposal and leave the chains idle; a graph launch then starts at slot parity 0 again.
     if ((rc = magi_launch_prepare(h, n_chains, h->stream))) return rc;
-    if ((rc = magi_launch_stream(h, n_chains, h->stream))) return rc;
-    if ((rc = magi_launch_tail(h, n_chains, h->stream))) return rc;
+    for (int sl = 0; sl < 2; ++sl) {
+        if ((rc = magi_launch_stream(h, n_chains, sl, true, h->stream))) return rc;
+        if ((rc = magi_launch_point(h, n_chains, sl, h->stream))) return rc;
+    }
     MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     h->epoch = 0;
     h->sampler_ready = true;
@@ -447,8 +448,6 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
     g.stop_k = std::min(h->cfg.total, kmin + n_steps);
     g.epoch = ++h->epoch;
     MAGI_HIP_CHECK(h, hipMemcpyAsync(h->ch.gctl, &g, sizeof(GlobalCtl), hipMemcpyHostToDevice, h->stream));
-    // workgroups that saw all_done flip in the middle of the previous run's last launch left partial ticket counts
-    MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.ticket, 0, sizeof(int) * h->n_chains, h->stream));
     MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));   // &g is pageable stack memory
     MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t0, h->stream));
 
@@ -464,8 +463,8 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
                 MAGI_HIP_CHECK(h, hipGraphLaunch(h->graph_exec, h->stream));
             } else {
                 for (int sl = 0; sl < kGraphSlots; ++sl) {
-                    if ((rc = magi_launch_stream(h, h->n_chains, h->stream))) return rc;
-                    if ((rc = magi_launch_tail(h, h->n_chains, h->stream))) return rc;
+                    if ((rc = magi_launch_stream(h, h->n_chains, sl & 1, true, h->stream))) return rc;
+                    if ((rc = magi_launch_point(h, h->n_chains, sl & 1, h->stream))) return rc;
                 }
             }
             MAGI_HIP_CHECK(h, hipMemcpyAsync(&h->h_gctl[slot], h->ch.gctl, sizeof(GlobalCtl), hipMemcpyDeviceToHost, h->stream));
@@ -646,9 +645,9 @@ int magi_time_gradient(magi_handle* h, int n_chains, int reps, double* total_ms_
             for (int i = 0; i < reps; ++i) {
                 if (ph <= 3) rc = magi_launch_phase(h, ph, n_chains, h->stream);
                 else if (ph == 4) rc = magi_launch_finalize(h, n_chains, h->d_fin, h->stream);
-                else if (ph == 5) rc = magi_launch_stream(h, n_chains, h->stream);
+                else if (ph == 5) rc = magi_launch_stream(h, n_chains, 0, false, h->stream);
                 else if (ph == 6) rc = magi_launch_leap_finalize(h, n_chains, h->d_fin, h->stream);
-                else rc = magi_launch_point(h, n_chains, h->stream);
+                else rc = magi_launch_point(h, n_chains, 0, h->stream);
                 if (rc) return rc;
             }
             MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t1, h->stream));

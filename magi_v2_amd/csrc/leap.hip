@@ -1,29 +1,16 @@
 // k_stream: the sampler's streaming kernel -- the four single-phase mat-vecs of a gradient
 //     hx = FH xc,  ex = FE xc,  etf = FE^T f,  kf = FK f        (xc = X - mu, f = drift(X, theta))
 // over the packed 128 x 128 operator blocks (pack.hip): the lower block triangle of the symmetric FH and FK
-// and every block of FE, each block serving a row-type and a column-type product in one pass.  The point
-// phase (leap_point.h) and the decisions (sampler.hip) follow in k_tail.
+// and every block of FE, each block serving a row-type and a column-type product in one pass.  A leapfrog slot
+// is the kernel pair [k_stream, k_point]; the decisions of slot s - 1 (decide.h) ride in k_stream(s) as one extra
+// workgroup per chain, off the critical path, and the stream itself assumes "same subtree, next leaf".
 // (reference arithmetic: magi_v2.py:308-348)
 #include "magi_internal.h"
 #include "leap_reduce.h"
 #include "leap_point.h"
+#include "decide.h"
 
 namespace {
-
-// extra block of the streaming kernel: the data-independent uniform draws of the leaf in flight, so the
-// tail starts with them in memory instead of evaluating two fp64 log1p on its critical path
-template <int NC>
-__device__ __forceinline__ void leap_service(const DevChains& ch, int c0) {
-    const int t = threadIdx.x;
-    if (t < NC && c0 + t < ch.n_chains) {
-        const LeafPlan lp = ch.plan[c0 + t];
-        if (lp.active && lp.leaf) {
-            double* par = ch.par + (size_t)(c0 + t) * PAR_COUNT;
-            par[PAR_ULEAF] = m_log1p(-rng_uniform(lp.leaf_ctr, lp.step_k, lp.chain_id, STREAM_LEAF, lp.seed));
-            par[PAR_UMERGE] = m_log1p(-rng_uniform(lp.depth, lp.step_k, lp.chain_id, STREAM_MERGE, lp.seed));
-        }
-    }
-}
 
 __device__ __forceinline__ double sel4(const double (&a)[MAGI_MAX_D], int d) {
     return d == 0 ? a[0] : d == 1 ? a[1] : d == 2 ? a[2] : a[3];
@@ -75,45 +62,80 @@ constexpr int ST_RW = MAGI_TB / ST_WAVES;      // rows of the block per wave
 // where v is xc = X_d - mu_d or f_d = drift_d(X, theta) as the operator requires (evaluated on the fly from the
 // state vector).  The partials go to tpart[chain][vec][d][other block][i]; k_point adds them in fixed order.
 template <int NC, int DRIFT>
-__global__ __launch_bounds__(64 * ST_WAVES) __attribute__((amdgpu_waves_per_eu(ST_WAVES == 8 ? (NC <= 2 ? 4 : 2) : (NC == 1 ? 4 : NC == 2 ? 3 : 2)))) void k_stream(DevProblem pb, DevChains ch) {
+__global__ __launch_bounds__(64 * ST_WAVES) __attribute__((amdgpu_waves_per_eu(NC <= 2 ? 3 : 2)))
+void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     using DR = DriftT<DRIFT>;
     constexpr int D = DR::D, P = DR::P, TB = MAGI_TB;
     if (ch.gctl->all_done) return;
     const int c0 = blockIdx.y * NC;
-    if ((int)blockIdx.x == pb.n_tasks) { leap_service<NC>(ch, c0); return; }
-#ifdef MAGI_TAIL_STAMPS
-    if (blockIdx.x == 0 && threadIdx.x == 0) ch.par[(size_t)c0 * PAR_COUNT + 40 + 7] = (double)__builtin_amdgcn_s_memrealtime();
-    if ((int)blockIdx.x == pb.n_tasks - 1 && threadIdx.x == 0) ch.par[(size_t)c0 * PAR_COUNT + 40 + 10] = (double)__builtin_amdgcn_s_memrealtime();
-#endif
     __shared__ double vcol[NC][TB], vrow[NC][TB], rowout[NC][TB], colacc[ST_WAVES][NC][TB];
+    __shared__ double th_s[NC][MAGI_MAX_P];
+    const int n_dec = (int)gridDim.x - pb.n_tasks;        // decision workgroups come FIRST in dispatch order: their one round of
+    if ((int)blockIdx.x < n_dec) {                         // loads is then on the wire before the stream saturates the memory system
+        // ---- the decisions of the previous slot, one workgroup per chain, next to this slot's stream (decide.h) ----
+        __shared__ double dsh[25 * 16], dshs[24];
+        __shared__ ChainCtl s_ctl;
+        __shared__ int s_g[2];
+        __shared__ double s_par[PAR_COUNT];
+        __shared__ double s_ops[OPS_COUNT * OPS_W];
+        const int chain = c0 + (int)blockIdx.x;
+        if (chain < ch.n_chains) decide_block<DRIFT>(pb, ch, cfg, chain, parity, dsh, dshs, &s_ctl, s_g, s_par, s_ops);
+        return;
+    }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int4 task = reinterpret_cast<const int4*>(pb.tasks)[blockIdx.x];
+    const int tix = (int)blockIdx.x - n_dec;
+    const int4 task = reinterpret_cast<const int4*>(pb.tasks)[tix];
     const int d = task.x, kind = task.y, bi = task.z, bj = task.w;
     const int N = pb.N;
 
-    // operands of this thread's vector entry (issued before the tile stream so that their wait does not
-    // cover the 32 row loads behind them)
+    // What to evaluate for each chain, from the plan the point phase executed LAST (the decisions that complete it run
+    // concurrently and may not be read): a leaf -> assume the subtree continues: the speculative state in the other
+    // buffer, with theta' derived here exactly as the decisions derive it; a skip-type plan -> the buffer as is.
     const bool isrow = t >= TB;
     const int loc = (isrow ? t - TB : t) & (TB - 1);
     const int gi = (isrow ? bi : bj) * TB + loc;
     const bool wantf = isrow ? (kind != TK_FH) : (kind == TK_FK);
     const double mud = sel4(pb.mu, d);
-    double xin[NC][D], thv[NC][P];
+    double xin[NC][D];
     bool act[NC];
+    // (small loads first, the tile stream behind them: their wait then does not cover the row loads)
+    if (wave < NC) {
+        const int c = wave, cc = min(c0 + c, ch.n_chains - 1);
+        const LeafPlan* lp = ch.plan + (size_t)(parity ^ 1) * ch.n_chains + cc;
+        const bool derive = lp->active && !lp->skip && lp->leaf;
+        double thp = 0.0;
+        if (derive) {
+            const double* vb = ch.vec + vec_off(pb, cc, 0);
+            const double* part = ch.part + (size_t)cc * PART_K * ch.n_wg;
+            double tpp = 0.0;
+#pragma unroll
+            for (int k = 0; k < P; ++k) { const double r = part_row_sum(part, ch.n_wg, PK_TP + k, lane); if (lane == k) tpp = r; }
+            if (lane < P) {
+                const int e = pb.ND + D + lane;
+                const double qv = (vb + (size_t)(V_Q + lp->cur) * pb.dimp)[e], pv = (vb + (size_t)(V_P + lp->cur) * pb.dimp)[e];
+                const double ex = m_exp(qv);
+                const double sg = ex / (1.0 + ex);                       // == par[PAR_SGT] of that state (compute_par_entry)
+                const double qnx = next_entry_pre(pv, qv, lp->hs, lp->eps, theta_entry_grad(pb.beta_inv, tpp, sg));
+                thp = m_log(1.0 + m_exp(qnx));                           // == par'[PAR_TH] (compute_par_entry)
+            }
+        } else if (lane < P) {
+            thp = ch.par[(size_t)cc * PAR_COUNT + PAR_TH + lane];
+        }
+        if (lane < P) th_s[c][lane] = thp;
+    }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int cc = min(c0 + c, ch.n_chains - 1);
-        const LeafPlan* lp = ch.plan + cc;
+        const LeafPlan* lp = ch.plan + (size_t)(parity ^ 1) * ch.n_chains + cc;
         act[c] = (c0 + c < ch.n_chains) && lp->active != 0;
-        const double* q = ch.vec + vec_off(pb, cc, V_Q + lp->cur);
+        const int buf = (lp->skip || !lp->leaf) ? lp->cur : (lp->cur ^ 1);
+        const double* q = ch.vec + vec_off(pb, cc, V_Q + buf);
 #pragma unroll
         for (int dd = 0; dd < D; ++dd) xin[c][dd] = q[dd * N + min(gi, N - 1)];
-#pragma unroll
-        for (int k = 0; k < P; ++k) thv[c][k] = ch.par[(size_t)cc * PAR_COUNT + PAR_TH + k];
     }
 
     // the wave's rows in chunks of 8, two chunks in flight (a0 / a1): 16 KB per wave on the wire while one chunk is in the ALUs
-    const double2* A = reinterpret_cast<const double2*>(pb.tiles + (size_t)blockIdx.x * TB * TB + (size_t)(wave * ST_RW) * TB) + lane;
+    const double2* A = reinterpret_cast<const double2*>(pb.tiles + (size_t)tix * TB * TB + (size_t)(wave * ST_RW) * TB) + lane;
     constexpr int NCK = ST_RW / 8;
     double2 a0[8], a1[8];
 #pragma unroll
@@ -121,6 +143,12 @@ __global__ __launch_bounds__(64 * ST_WAVES) __attribute__((amdgpu_waves_per_eu(S
 #pragma unroll
     for (int r = 0; r < 8; ++r) a1[r] = A[(size_t)(8 + r) * (TB / 2)];
     __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                 // th_s
+    double thv[NC][P];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int k = 0; k < P; ++k) thv[c][k] = th_s[c][k];
 
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -190,22 +218,26 @@ __global__ __launch_bounds__(64 * ST_WAVES) __attribute__((amdgpu_waves_per_eu(S
     }
 }
 
-// ---- point kernel (validation entry; the sampler runs the same point_block inside k_tail) ---------------------------
+// ---- point kernel: the elementwise half of slot `parity` (leap_point.h), N / 16 workgroups per chain -------------------------
 template <int DRIFT>
-__global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains ch) {
+__global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains ch, int parity) {
     if (ch.gctl->all_done) return;
     __shared__ double res[PT_POINTS * 4 * 4];
     __shared__ double redk[64 * PART_K];
-    if (!ch.plan[blockIdx.y].active) return;
-    point_block<DRIFT>(pb, ch, blockIdx.y, blockIdx.x, res, redk);
+    const LeafPlan lp = ch.plan[(size_t)parity * ch.n_chains + blockIdx.y];
+    if (!lp.active || lp.skip) return;
+    point_block<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, res, redk);
 }
 
-// validation / bootstrap plan: evaluate buffer 0, no leapfrog
+// validation plan (magi_logpost_grad_fused / timing): slot 0 evaluates buffer 0 as is, no leapfrog
 __global__ void k_plan_eval(DevChains ch) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ch.n_chains) return;
+    LeafPlan prev{};
+    prev.active = 1; prev.skip = 1;           // what k_stream(parity 0) reads: "evaluate buffer 0 as is"
+    ch.plan[(size_t)ch.n_chains + c] = prev;
     LeafPlan p{};
-    p.active = 1;
+    p.active = 1;                             // what k_point(parity 0) executes: gradient only
     ch.plan[c] = p;
 }
 
@@ -216,7 +248,10 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_leap_finalize(DevProblem 
     const int c = blockIdx.x;
     double* vb = ch.vec + vec_off(pb, c, 0);
     const LeafPlan lp = ch.plan[c];
-    const ReduceOut ro = leap_reduce<DRIFT>(pb, ch, c, vb, ch.par + (size_t)c * PAR_COUNT, lp, sh, shs);
+    double pre[RedLayout<DRIFT>::PER_WAVE];
+    leap_reduce_issue<DRIFT>(ch, c, pre);
+    double* par = ch.par + (size_t)c * PAR_COUNT;
+    const ReduceOut ro = leap_reduce<DRIFT>(pb, ch, c, vb, par, par, lp, pre, sh, shs);
     if (threadIdx.x == 0 && out) {
         out[c * 8 + 0] = ro.L;
         out[c * 8 + 1] = ro.t12;
@@ -227,18 +262,18 @@ __global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_leap_finalize(DevProblem 
 }
 
 template <int NC, int DRIFT>
-int launch_stream_nd(magi_handle* h, int n_chains, hipStream_t s) {
+int launch_stream_nd(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s) {
     const DevProblem& pb = h->pb;
-    const dim3 grid(pb.n_tasks + 1, (n_chains + NC - 1) / NC);      // + the service block
-    hipLaunchKernelGGL((k_stream<NC, DRIFT>), grid, dim3(64 * ST_WAVES), 0, s, pb, h->ch);
+    const dim3 grid(pb.n_tasks + (with_decisions ? NC : 0), (n_chains + NC - 1) / NC);      // + one decision workgroup per chain
+    hipLaunchKernelGGL((k_stream<NC, DRIFT>), grid, dim3(64 * ST_WAVES), 0, s, pb, h->ch, h->cfg, parity);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("stream launch: ") + hipGetErrorString(e));
     return MAGI_OK;
 }
 
 template <int NC>
-int launch_stream_nc(magi_handle* h, int n_chains, hipStream_t s) {
-#define MAGI_CALL(DR) return launch_stream_nd<NC, DR>(h, n_chains, s)
+int launch_stream_nc(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s) {
+#define MAGI_CALL(DR) return launch_stream_nd<NC, DR>(h, n_chains, parity, with_decisions, s)
     MAGI_DRIFT_DISPATCH(h->pb.drift, MAGI_CALL);
 #undef MAGI_CALL
     return MAGI_OK;
@@ -248,27 +283,21 @@ int launch_stream_nc(magi_handle* h, int n_chains, hipStream_t s) {
 
 int magi_leap_wgs(const DevProblem& pb) { return (pb.N + PT_POINTS - 1) / PT_POINTS; }
 
-int magi_launch_stream(magi_handle* h, int n_chains, hipStream_t s) {
-    if (n_chains >= 3) return launch_stream_nc<4>(h, n_chains, s);
-    if (n_chains == 2) return launch_stream_nc<2>(h, n_chains, s);
-    return launch_stream_nc<1>(h, n_chains, s);
+int magi_launch_stream(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s) {
+    if (n_chains >= 3) return launch_stream_nc<4>(h, n_chains, parity, with_decisions, s);
+    if (n_chains == 2) return launch_stream_nc<2>(h, n_chains, parity, with_decisions, s);
+    return launch_stream_nc<1>(h, n_chains, parity, with_decisions, s);
 }
 
-int magi_launch_point(magi_handle* h, int n_chains, hipStream_t s) {
+int magi_launch_point(magi_handle* h, int n_chains, int parity, hipStream_t s) {
     const DevProblem& pb = h->pb;
     const dim3 g(magi_leap_wgs(pb), n_chains), b(PT_THREADS);
-#define MAGI_CALL(DR) hipLaunchKernelGGL(k_point<DR>, g, b, 0, s, pb, h->ch)
+#define MAGI_CALL(DR) hipLaunchKernelGGL(k_point<DR>, g, b, 0, s, pb, h->ch, parity)
     MAGI_DRIFT_DISPATCH(pb.drift, MAGI_CALL);
 #undef MAGI_CALL
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("point launch: ") + hipGetErrorString(e));
     return MAGI_OK;
-}
-
-int magi_launch_leap(magi_handle* h, int n_chains, hipStream_t s) {
-    int rc = magi_launch_stream(h, n_chains, s);
-    if (rc == MAGI_OK) rc = magi_launch_point(h, n_chains, s);
-    return rc;
 }
 
 int magi_launch_plan_eval(magi_handle* h, int n_chains, hipStream_t s) {

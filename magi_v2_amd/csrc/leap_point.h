@@ -81,35 +81,34 @@ struct GridPoint {     // component d of grid index i of one chain (one lane)
             d4 = 2.0 * df / o.sig2;
         }
         const double gx = -0.5 * (pb.beta_inv * (2.0 * hx - 2.0 * etf + jtd) + d4);
-        st_agent(vb + (size_t)V_G * dimp + e, gx);
+        *(vb + (size_t)V_G * dimp + e) = gx;
         if (lp.leaf) {
             double* rho = vb + (size_t)V_RHOSUB * dimp;
             double* ckp = vb + (size_t)V_CKP0 * dimp;
             double* ckr = vb + (size_t)V_CKRHO0 * dimp;
             const double pn = o.phe + lp.hs * gx;
-            st_agent(vb + (size_t)V_PLEAF * dimp + e, pn);
+            *(vb + (size_t)V_PLEAF * dimp + e) = pn;
             const double rs = o.rhoe + pn;
-            st_agent(rho + e, rs);
+            *(rho + e) = rs;
             pk[PK_PP] = pn * pn;
-            if (lp.even) { st_agent(ckp + (size_t)lp.ck_slot * dimp + e, pn); st_agent(ckr + (size_t)lp.ck_slot * dimp + e, rs); }
+            if (lp.even) { *(ckp + (size_t)lp.ck_slot * dimp + e) = pn; *(ckr + (size_t)lp.ck_slot * dimp + e) = rs; }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k < lp.nchk) { const double df = rs - o.crk[k]; pk[PK_DOT + 2 * k] = df * o.cpk[k]; pk[PK_DOT + 2 * k + 1] = df * pn; }
             const double pnext = pn + lp.hs * gx;
-            st_agent(vb + (size_t)(V_P + (lp.cur ^ 1)) * dimp + e, pnext);
-            st_agent(vb + (size_t)(V_Q + (lp.cur ^ 1)) * dimp + e, xd + lp.eps * pnext);
+            *(vb + (size_t)(V_P + (lp.cur ^ 1)) * dimp + e) = pnext;
+            *(vb + (size_t)(V_Q + (lp.cur ^ 1)) * dimp + e) = xd + lp.eps * pnext;
         }
     }
 };
 
 // All PT_THREADS threads of the block must call it.  res: PT_POINTS*4*4 doubles, redk: 64*PART_K doubles of LDS.
-// Writes part[cc][k][blk].  The chain's plan must be active.
+// Writes part[cc][k][blk].  `lp`: the chain's plan for this slot (active, not skip).
 template <int DRIFT>
-__device__ __forceinline__ void point_block(const DevProblem& pb, const DevChains& ch, int cc, int blk, double* res, double* redk) {
+__device__ __forceinline__ void point_block(const DevProblem& pb, const DevChains& ch, const LeafPlan& lp, int cc, int blk, double* res, double* redk) {
     using GP = GridPoint<DRIFT>;
     constexpr int D = GP::D, TB = MAGI_TB;
     const int t = threadIdx.x;
-    const LeafPlan lp = ch.plan[cc];
     // finishing lanes: t < 64 = (component, point)
     const int fpt = t & (PT_POINTS - 1), fd = (t >> 4) & 3;
     const int fi = blk * PT_POINTS + fpt;
@@ -151,6 +150,6 @@ __device__ __forceinline__ void point_block(const DevProblem& pb, const DevChain
         double s = 0.0;
 #pragma unroll 8
         for (int u = 0; u < 64; ++u) s += redk[u * PART_K + t];
-        st_agent(&ch.part[((size_t)cc * PART_K + t) * ch.n_wg + blk], s);
+        *(&ch.part[((size_t)cc * PART_K + t) * ch.n_wg + blk]) = s;
     }
 }

@@ -25,20 +25,76 @@ static __shared__ double g_stamps[16];
 
 constexpr int PK_T12 = 0, PK_SS = 1, PK_TP = 5, PK_PP = 11, PK_DOT = 12;
 
+// ---- pieces shared bit for bit by the decisions (below) and by k_stream, which derives the next theta itself ----
+// sum of one PART row over the point workgroups: whole wave, lane = workgroup, fixed order
+__device__ __forceinline__ double part_row_sum(const double* part, int nwg, int row, int lane) {
+    double v = 0.0;
+    for (int w = lane; w < nwg; w += 64) v += part[(size_t)row * nwg + w];
+    return wave_sum(v);
+}
+// d L / d theta_pre_p from the global sum tp_p (magi_v2.py:318-323, 335-337 chained through softplus)
+__device__ __forceinline__ double theta_entry_grad(double beta_inv, double tpp, double sg) { return -0.5 * beta_inv * tpp * sg + (1.0 - sg); }
+// position of a parameter entry after completing this leaf's momentum step and taking the next half step
+__device__ __forceinline__ double next_entry_pre(double ph, double q, double hs, double eps, double gj) {
+    const double pn = ph + hs * gj;
+    return q + eps * (pn + hs * gj);
+}
+
 struct ReduceOut {
     double L, t12, t3, t4, pp;
     double dA[4], dB[4];
 };
 
-// sh: (21 + 4) * 16 doubles (block_sum scratch + a 64-double parking block), shs: >= 16 doubles.  `lp` is the plan the streaming kernel just executed.
+// The workgroup partials of one chain, loaded with NO dependence on the plan (so the decisions can issue them together
+// with their control state): wave w owns values k = w, w + 4, ...; lane = workgroup.  4 waves per block.
+constexpr int RED_WAVES = 4;
+template <int DRIFT> struct RedLayout {
+    static constexpr int D = DriftT<DRIFT>::D, P = DriftT<DRIFT>::P;
+    static constexpr int K0 = 2 + D + P;            // t12, ss, tp, pp  (red[]: [0] t12, [1..D] ss, [1+D..] tp, [1+D+P] pp, [K0..] dots)
+    static constexpr int PER_WAVE = (K0 + 8 + RED_WAVES - 1) / RED_WAVES;
+    static __device__ __forceinline__ int row(int k) {
+        return (k == 0) ? PK_T12 : (k <= D) ? PK_SS + (k - 1) : (k <= D + P) ? PK_TP + (k - 1 - D) : (k == 1 + D + P) ? PK_PP : PK_DOT + (k - K0);
+    }
+};
+
 template <int DRIFT>
-__device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const DevChains& ch, int chain, double* vb, double* par,
-                                                 const LeafPlan& lp, double* sh, double* shs) {
+__device__ __forceinline__ void leap_reduce_issue(const DevChains& ch, int chain, double (&v)[RedLayout<DRIFT>::PER_WAVE]) {
+    using RL = RedLayout<DRIFT>;
+    const double* part = ch.part + (size_t)chain * PART_K * ch.n_wg;      // [PART_K][n_wg]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwg = ch.n_wg;
+#pragma unroll
+    for (int i = 0; i < RL::PER_WAVE; ++i) {
+        const int k = wave + RED_WAVES * i;
+        double a = 0.0;
+        if (k < RL::K0 + 8)
+            for (int w = lane; w < nwg; w += 64) a += part[(size_t)RL::row(k) * nwg + w];      // (same order as part_row_sum)
+        v[i] = a;
+    }
+}
+
+// The parameter entries (index >= N D) of every vector the reduce may need, whatever the plan says: both momentum /
+// position buffers, the subtree momentum sum and all checkpoints -> LDS [OPS_COUNT][OPS_W].
+constexpr int OPS_P = 0, OPS_Q = 2, OPS_RHO = 4, OPS_CKP = 5, OPS_CKR = OPS_CKP + MAGI_MAX_DEPTH, OPS_COUNT = OPS_CKR + MAGI_MAX_DEPTH;
+constexpr int OPS_W = 12;      // >= MAGI_MAX_D + MAGI_MAX_P entries per vector
+__device__ __forceinline__ void reduce_prefetch_ops(const DevProblem& pb, const double* vb, int n_entries, double* ops) {
+    for (int idx = threadIdx.x; idx < OPS_COUNT * OPS_W; idx += blockDim.x) {
+        const int slot = idx / OPS_W, j = idx - slot * OPS_W;
+        if (j >= n_entries) continue;
+        const int vs = slot < OPS_Q ? V_P + slot : slot < OPS_RHO ? V_Q + (slot - OPS_Q) : slot == OPS_RHO ? V_RHOSUB
+                     : slot < OPS_CKR ? V_CKP0 + (slot - OPS_CKP) : V_CKRHO0 + (slot - OPS_CKR);
+        ops[idx] = vb[(size_t)vs * pb.dimp + pb.ND + j];
+    }
+}
+
+// sh: (21 + 4) * 16 doubles (scratch + a 64-double parking block), shs: >= 16 doubles.  `lp` is the plan the point phase just
+// executed; `pre` the values of leap_reduce_issue; `par_r` the state's parameter block (may be an LDS copy), `par` the global one.
+template <int DRIFT>
+__device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const DevChains& ch, int chain, double* vb, double* par, const double* par_r,
+                                                 const LeafPlan& lp, const double (&pre)[RedLayout<DRIFT>::PER_WAVE], double* sh, double* shs,
+                                                 const double* ops = nullptr /* LDS copy made by reduce_prefetch_ops, or null */) {
     using DR = DriftT<DRIFT>;
     constexpr int D = DR::D, P = DR::P;
     const int ND = pb.ND, dimp = pb.dimp;
-    const double* part = ch.part + (size_t)chain * PART_K * ch.n_wg;      // [PART_K][n_wg]
-    const int nwg = ch.n_wg;
 
     // parameter entries (lanes j < D + P of wave 0): operands fetched early, used after the reduce
     const int j = threadIdx.x;
@@ -55,28 +111,38 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
     double* ckr = vb + (size_t)V_CKRHO0 * dimp;
     double pj = 0.0, rj = 0.0, qj = 0.0, cpj[4] = {0.0, 0.0, 0.0, 0.0}, crj[4] = {0.0, 0.0, 0.0, 0.0};
     if (plane && leaf) {
-        pj = ph[ND + j];
-        rj = rho[ND + j];
-        qj = q[ND + j];
+        if (ops) {
+            pj = ops[(OPS_P + lp.cur) * OPS_W + j];
+            qj = ops[(OPS_Q + lp.cur) * OPS_W + j];
+            rj = ops[OPS_RHO * OPS_W + j];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < lp.nchk) { cpj[k] = ckp[(size_t)lp.chk_slot[k] * dimp + ND + j]; crj[k] = ckr[(size_t)lp.chk_slot[k] * dimp + ND + j]; }
+            for (int k = 0; k < 4; ++k)
+                if (k < lp.nchk) { cpj[k] = ops[(OPS_CKP + lp.chk_slot[k]) * OPS_W + j]; crj[k] = ops[(OPS_CKR + lp.chk_slot[k]) * OPS_W + j]; }
+        } else {
+            pj = ph[ND + j];
+            rj = rho[ND + j];
+            qj = q[ND + j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < lp.nchk) { cpj[k] = ckp[(size_t)lp.chk_slot[k] * dimp + ND + j]; crj[k] = ckr[(size_t)lp.chk_slot[k] * dimp + ND + j]; }
+        }
     }
 
-    // ---- add the workgroup partials: wave w owns values k = w, w + nw, ...; lane = workgroup (fixed order) ---------
-    constexpr int K0 = 2 + D + P;            // t12, ss, tp, pp  (layout of red[]: [0] t12, [1..D] ss, [1+D..] tp, [1+D+P] pp, [K0..] dots)
+    // log(2 pi sigma_d^2) of the evaluated state: a third wave computes it while the partial sums are being added (keeping this
+    // fp64 log out of the chain  exp -> log -> log  that produces the next state's parameters below)
+    if (threadIdx.x >= 128 && threadIdx.x < 128 + D) shs[12 + (threadIdx.x - 128)] = m_log(2.0 * 3.141592653589793 * par_r[PAR_SIG2 + (threadIdx.x - 128)]);
+
+    // ---- add the workgroup partials (fixed order: lane = workgroup, butterfly) ------------------------------------------
+    constexpr int K0 = 2 + D + P;
     double red[K0 + 8];
     const bool dots = leaf && lp.nchk > 0;
     {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-        const int nval = dots ? K0 + 8 : K0;
-        for (int k = wave; k < nval; k += nw) {
-            // red index -> PART row
-            const int row = (k == 0) ? PK_T12 : (k <= D) ? PK_SS + (k - 1) : (k <= D + P) ? PK_TP + (k - 1 - D) : (k == 1 + D + P) ? PK_PP : PK_DOT + (k - K0);
-            double v = 0.0;
-            for (int w = lane; w < nwg; w += 64) v += ld_agent(&part[(size_t)row * nwg + w]);
-            v = wave_sum(v);
-            if (lane == 0) sh[k] = v;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < RedLayout<DRIFT>::PER_WAVE; ++i) {
+            const int k = wave + RED_WAVES * i;
+            const double v = wave_sum(pre[i]);
+            if (lane == 0 && k < K0 + 8) sh[k] = v;
         }
         __syncthreads();
 #pragma unroll
@@ -89,18 +155,18 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
     if (threadIdx.x < 64) {
         double t3 = 0.0, t4 = 0.0, lj = 0.0, gj = 0.0;
         if (j < D) {
-            const double sg = par[PAR_SGS + j], sj = par[PAR_SIG2 + j];
+            const double sg = par_r[PAR_SGS + j], sj = par_r[PAR_SIG2 + j];
             const double ssd = select_lane<K0 + 8>(red, 1, D, j);
             const double nds = (j == 0) ? pb.N_ds[0] : (j == 1) ? pb.N_ds[1] : (j == 2) ? pb.N_ds[2] : pb.N_ds[3];
-            t3 = nds * par[PAR_LOG2PIS + j];
+            t3 = nds * shs[12 + j];
             t4 = ssd * (1.0 / sj);
-            lj = par[PAR_LJS + j];
+            lj = par_r[PAR_LJS + j];
             gj = -0.5 * (nds / sj - ssd / (sj * sj)) * sg + (1.0 - sg);
         } else if (plane) {
-            const double sg = par[PAR_SGT + (j - D)];
+            const double sg = par_r[PAR_SGT + (j - D)];
             const double tpp = select_lane<K0 + 8>(red, 1 + D, P, j - D);
-            lj = par[PAR_LJT + (j - D)];
-            gj = -0.5 * pb.beta_inv * tpp * sg + (1.0 - sg);
+            lj = par_r[PAR_LJT + (j - D)];
+            gj = theta_entry_grad(pb.beta_inv, tpp, sg);
         }
         double ppj = 0.0, a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
         if (plane) {
@@ -141,19 +207,19 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
         if (jj < D + P) {
             double gj;
             if (jj < D) {
-                const double sg = par[PAR_SGS + jj], sj = par[PAR_SIG2 + jj];
+                const double sg = par_r[PAR_SGS + jj], sj = par_r[PAR_SIG2 + jj];
                 const double ssd = select_lane<K0 + 8>(red, 1, D, jj);
                 const double nds = (jj == 0) ? pb.N_ds[0] : (jj == 1) ? pb.N_ds[1] : (jj == 2) ? pb.N_ds[2] : pb.N_ds[3];
                 gj = -0.5 * (nds / sj - ssd / (sj * sj)) * sg + (1.0 - sg);
             } else {
-                const double sg = par[PAR_SGT + (jj - D)];
+                const double sg = par_r[PAR_SGT + (jj - D)];
                 const double tpp = select_lane<K0 + 8>(red, 1 + D, P, jj - D);
-                gj = -0.5 * pb.beta_inv * tpp * sg + (1.0 - sg);
+                gj = theta_entry_grad(pb.beta_inv, tpp, sg);
             }
-            const double pn = ph[ND + jj] + lp.hs * gj;
-            const double qnx = q[ND + jj] + lp.eps * (pn + lp.hs * gj);
+            const double phv = ops ? ops[(OPS_P + lp.cur) * OPS_W + jj] : ph[ND + jj], qv = ops ? ops[(OPS_Q + lp.cur) * OPS_W + jj] : q[ND + jj];
+            const double qnx = next_entry_pre(phv, qv, lp.hs, lp.eps, gj);
             // the old entries are still needed by wave 0 -> park the new ones, publish after the barrier
-            compute_par_entry(pb, jj, qnx, sh + 21 * 16);      // parking block of 64 doubles behind block_sum's scratch
+            compute_par_entry(pb, jj, qnx, sh + 21 * 16, false);      // parking block of 64 doubles behind block_sum's scratch
         }
     }
     __syncthreads();
@@ -162,7 +228,7 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
         const int k = threadIdx.x - 64;
         const bool used = (k < PAR_TH + P) || (k >= PAR_SGT && k < PAR_SGT + P) || (k >= PAR_LJT && k < PAR_LJT + P) ||
                           (k >= PAR_SIG2 && k < PAR_SIG2 + D) || (k >= PAR_SGS && k < PAR_SGS + D) ||
-                          (k >= PAR_LJS && k < PAR_LJS + D) || (k >= PAR_LOG2PIS && k < PAR_LOG2PIS + D);
+                          (k >= PAR_LJS && k < PAR_LJS + D);
         if (used) par[k] = sh[21 * 16 + k];
     }
     ReduceOut o;

@@ -128,6 +128,8 @@ struct GlobalCtl {
 // tail (or the host for API calls), read by every workgroup of k_leap_*.
 struct LeafPlan {
     int active;        // 0: leave the chain's state alone (idle chain)
+    int skip;          // 1: the state in buffer `cur` was set up by the decisions while this slot's stream was already
+                       //    running on something else: the point phase does nothing, the NEXT stream evaluates `cur` as is
     int leaf;          // 1: complete the leapfrog (momentum, sums, checkpoint, speculative next state)
     int cur;           // position / half-momentum buffer being evaluated (0/1)
     int even;          // write the U-turn checkpoint of this leaf
@@ -152,10 +154,9 @@ constexpr int PART_K = 24;   // partial sums per workgroup and chain: t12, ss[D]
 struct DevChains {
     double* vec;          // [n_chains][V_COUNT][dimp]
     ChainCtl* ctl;        // [n_chains]
-    LeafPlan* plan;       // [n_chains]
+    LeafPlan* plan;       // [2][n_chains] ring by slot parity: the point phase of slot s executes plan[s & 1]
     double* part;         // [n_chains][PART_K][n_wg] partial sums of the point kernel
     int n_wg;             // workgroups along the grid axis of k_point
-    int* ticket;          // [n_chains] workgroups of k_tail that have finished the point half of the slot
     double* tpart;        // [n_chains][4 (hx, ex, etf, kf)][D][nb][Np] block partials of the streaming kernel
     double* par;          // [n_chains][PAR_COUNT] transformed parameters of the state in V_Q
     GlobalCtl* gctl;
@@ -175,15 +176,6 @@ struct DevChains {
 __host__ __device__ inline size_t vec_off(const DevProblem& pb, int chain, int slot) {
     return ((size_t)chain * V_COUNT + (size_t)slot) * (size_t)pb.dimp;
 }
-
-// ------------------------------------------------------------------------------------------
-// Agent-scope accesses for data exchanged between workgroups INSIDE one kernel (k_tail: point workgroups ->
-// the workgroup that finishes last).  The L2 of each XCD is not coherent with the others: a write-through
-// store (sc1) lands at the device coherence point without a whole-L2 write-back fence, and an sc1 load
-// does not hit a stale line.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011), identical to oracle/magi_oracle.py::philox4x32
@@ -262,7 +254,7 @@ enum ParOff { PAR_TH = 0, PAR_SGT = 8, PAR_LJT = 16, PAR_SIG2 = 24, PAR_SGS = 28
               PAR_COUNT = 64 };
 
 // entry j of the parameter block: j < D -> sigma_pre[j], else theta_pre[j - D]
-__device__ inline void compute_par_entry(const DevProblem& pb, int j, double pre, double* par) {
+__device__ inline void compute_par_entry(const DevProblem& pb, int j, double pre, double* par, bool with_log2pis = true) {
     const double e = m_exp(pre);
     const double sp = m_log(1.0 + e);          // magi_v2.py:318-319
     const double sg = e / (1.0 + e);           // d softplus / d pre (= 1/(1+exp(-pre)) up to rounding)
@@ -272,7 +264,7 @@ __device__ inline void compute_par_entry(const DevProblem& pb, int j, double pre
         par[PAR_SIG2 + j] = s2;
         par[PAR_SGS + j] = sg;
         par[PAR_LJS + j] = pre - sp;
-        par[PAR_LOG2PIS + j] = m_log(2.0 * 3.141592653589793 * s2);
+        if (with_log2pis) par[PAR_LOG2PIS + j] = m_log(2.0 * 3.141592653589793 * s2);      // (leap_reduce evaluates it at the consumer)
     } else {
         const int p = j - pb.D;
         par[PAR_TH + p] = sp;
@@ -720,9 +712,8 @@ int magi_fail(magi_handle* h, int code, const std::string& msg);
 int magi_launch_gradient(magi_handle* h, int n_chains, hipStream_t s);        // phases 1-3
 int magi_launch_phase(magi_handle* h, int phase, int n_chains, hipStream_t s);
 int magi_launch_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s);
-int magi_launch_leap(magi_handle* h, int n_chains, hipStream_t s);             // k_stream + k_point
-int magi_launch_stream(magi_handle* h, int n_chains, hipStream_t s);           // single-phase block mat-vecs
-int magi_launch_point(magi_handle* h, int n_chains, hipStream_t s);            // leapfrog epilogue per grid point
+int magi_launch_stream(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s);   // k_stream: block mat-vecs of slot `parity` (+ decisions of the previous slot)
+int magi_launch_point(magi_handle* h, int n_chains, int parity, hipStream_t s);                            // k_point: leapfrog epilogue per grid point
 int magi_launch_leap_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s);
 int magi_leap_wgs(const DevProblem& pb);
 int magi_build_profile_get(double* flops, double* ms, long* calls);           // build.hip
@@ -733,7 +724,6 @@ int magi_launch_plan_eval(magi_handle* h, int n_chains, hipStream_t s);        /
 // build.hip: E = Ks M, H = Cs + M^T E for D dense [N][N] components (H overwrites Cs)
 int magi_fused_operators(magi_handle* h, int N, int D, double* dCs_inout_H, const double* dM, const double* dKs, double* dE);
 int magi_launch_prepare(magi_handle* h, int n_chains, hipStream_t s);   // fills par from V_Q
-int magi_launch_tail(magi_handle* h, int n_chains, hipStream_t s);
 int magi_launch_init_chains(magi_handle* h, const long long* d_chain_ids, hipStream_t s);
 int magi_ensure_chains(magi_handle* h, int n_chains);
 // build.hip: dense device matrices -> packed device storage (sym / transpose / band)

@@ -1,412 +1,7 @@
-// Device-resident NUTS / dual-averaging / annealing state machine.
-//
-// Replaces the TFP wiring of MAGI_v2.predict (magi_v2.py:357-396): NoUTurnSampler(step_size=0.1)
-// inside DualAveragingStepSizeAdaptation(int(0.8*burnin), 0.75), wrapped by LogAnnealedNUTS
-// (magi_v2.py:838-889, temperature schedule :833-835).  TFP itself is not in the reference tree;
-// its published algorithm (iterative tree doubling with multinomial sampling and the generalised
-// U-turn test, max_tree_depth 10, max_energy_diff 1000; Nesterov dual averaging) is restated in
-// oracle/magi_oracle.py and mirrored here decision for decision, with a shared Philox4x32-10 RNG.
-//
-// MI355X design: a leapfrog is the static kernel pair [k_stream (single-phase block mat-vecs), k_tail].
-// k_tail runs the point half of the slot (leap_point.h) on N/16 workgroups per chain; the workgroup
-// that finishes last (ticket counter) adds the partial sums, finishes the parameter entries, does
-// all tree bookkeeping (multinomial proposal, checkpointed U-turn tests, doubling, merge,
-// transition end, dual averaging, temperature, next momentum draw) and writes the NEXT position
-// to evaluate.  No decision ever returns to the host, so the host only replays one hipGraph of
-// 32 leapfrog slots and polls a control block; chains advance asynchronously, each using every
-// slot.  Energies follow TFP: energy = target - 0.5 p.p  (minus the Hamiltonian).
-//
-// The tail runs ONCE per launch on one CU, i.e. on a cold instruction cache: its speed is set by
-// code size along the executed path.  Hence: one instantiation per drift (compile-time D, P),
-// every big helper has a single call site, fp64 transcendentals are noinline, and the rare
-// transition-end work sits behind one branch at the bottom.
+// Chain initialisation of the device-resident sampler (the state machine itself is decide.h, run inside k_stream).
 #include "magi_internal.h"
-#include "leap_reduce.h"
-#include "leap_point.h"
 
 namespace {
-
-struct TailVecs {
-    double *q, *p, *g, *pL, *qL, *gL, *pR, *qR, *gR, *candq, *candg, *subq, *subg, *rho, *rhosub, *ckp, *ckrho;
-};
-
-__device__ __forceinline__ TailVecs tail_vecs(const DevProblem& pb, double* vb) {
-    const size_t s = pb.dimp;
-    TailVecs v;
-    v.q = vb + V_Q * s; v.p = vb + V_P * s; v.g = vb + V_G * s;
-    v.pL = vb + V_PL * s; v.qL = vb + V_QL * s; v.gL = vb + V_GL * s;
-    v.pR = vb + V_PR * s; v.qR = vb + V_QR * s; v.gR = vb + V_GR * s;
-    v.candq = vb + V_CANDQ * s; v.candg = vb + V_CANDG * s;
-    v.subq = vb + V_SUBQ * s; v.subg = vb + V_SUBG * s;
-    v.rho = vb + V_RHO * s; v.rhosub = vb + V_RHOSUB * s;
-    v.ckp = vb + V_CKP0 * s; v.ckrho = vb + V_CKRHO0 * s;
-    return v;
-}
-
-// DualAveragingStepSizeAdaptation.one_step after the inner NUTS step (oracle: dual_averaging_update).
-// Evaluated by one thread; results returned through out[0..3].
-__device__ __noinline__ void dual_averaging_eval(double target_accept, int n_adapt, int prev, double da_step_size, double da_error_sum,
-                                                double da_log_avg, double da_log_shrink, double e_sum, int lf_count, double* out) {
-    const double log_accept_ratio = m_log(e_sum / (double)lf_count);
-    double lap = isfinite(log_accept_ratio) ? log_accept_ratio : -INFINITY;
-    lap = fmin(lap, 0.0);
-    const double accept = (lap > -INFINITY) ? m_exp(lap) : 0.0;
-    const double t = (double)(prev + 1);
-    double new_err = da_error_sum + target_accept - accept;
-    const double soft_t = 10.0 + t;                              // step_count_smoothing
-    const double new_log_step = da_log_shrink - (new_err * sqrt(t)) / (soft_t * 0.05);   // exploration_shrinkage
-    const double eta = pow(t, -0.75);                            // decay_rate
-    double new_log_avg = eta * new_log_step + (1.0 - eta) * da_log_avg;
-    double new_ss;
-    if (prev < n_adapt) new_ss = m_exp(new_log_step);
-    else if (prev > n_adapt) new_ss = da_step_size;
-    else new_ss = m_exp(new_log_avg);
-    if (prev > n_adapt) { new_err = da_error_sum; new_log_avg = da_log_avg; }
-    out[0] = log_accept_ratio;
-    out[1] = new_ss;
-    out[2] = new_err;
-    out[3] = new_log_avg;
-}
-
-// plan of the leaf with index c.it of the current subtree (evaluated from buffer c.cur)
-__device__ __forceinline__ LeafPlan make_leaf_plan(const ChainCtl& c, unsigned long long seed, bool hmc) {
-    LeafPlan p{};
-    p.active = 1;
-    p.leaf = 1;
-    p.cur = c.cur;
-    const int it = c.it;
-    p.even = (!hmc && (it & 1) == 0) ? 1 : 0;
-    p.ck_slot = __popc((unsigned)it);
-    int nk = 0;
-    if (!hmc && (it & 1) != 0)
-        for (int kk = 1; ((it + 1) & ((1 << kk) - 1)) == 0 && (1 << kk) <= c.nsteps; ++kk) nk = kk;
-    p.nchk = min(nk, 4);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) p.chk_slot[k] = (k < p.nchk) ? __popc((unsigned)(it + 1 - (2 << k))) : 0;
-    p.eps = c.dir * c.eps;
-    p.hs = 0.5 * p.eps * c.beta_k;
-    p.leaf_ctr = (unsigned)c.leaf_ctr;
-    p.depth = (unsigned)c.depth;
-    p.step_k = (unsigned)c.k;
-    p.chain_id = (unsigned)c.chain_id;
-    p.seed = seed;
-    return p;
-}
-
-template <int DRIFT>
-__global__ __launch_bounds__(PT_THREADS) void k_tail(DevProblem pb, DevChains ch, SamplerCfgDev cfg) {
-    __shared__ double sh[25 * 16];
-    __shared__ double shs[24];
-    __shared__ double pres[PT_POINTS * 4 * 4];
-    __shared__ double predk[64 * PART_K];
-    __shared__ int s_last;
-    __shared__ ChainCtl s_ctl;
-    __shared__ int s_g[2];
-    if (ch.gctl->all_done) return;
-    const int chain = blockIdx.y;
-    const int tid = threadIdx.x;
-    // the decision state is fetched now, next to the point phase's loads, so that the workgroup that turns out to be
-    // last does not start with a round trip to memory (nobody writes it before that workgroup itself does)
-    static_assert(sizeof(ChainCtl) % 4 == 0 && sizeof(ChainCtl) / 4 <= PT_THREADS - 2, "ChainCtl prefetch");
-    if (tid < (int)(sizeof(ChainCtl) / 4)) reinterpret_cast<int*>(&s_ctl)[tid] = reinterpret_cast<const int*>(ch.ctl + chain)[tid];
-    else if (tid == PT_THREADS - 2) s_g[0] = ch.gctl->stop_k;
-    else if (tid == PT_THREADS - 1) s_g[1] = ch.gctl->epoch;
-#ifdef MAGI_TAIL_STAMPS
-    const double st_entry = (double)__builtin_amdgcn_s_memrealtime();
-#endif
-    // ---- point half of the slot on every workgroup; the LAST one to finish goes on to the decisions -------------
-    if (ch.plan[chain].active) point_block<DRIFT>(pb, ch, chain, blockIdx.x, pres, predk);
-#ifdef MAGI_TAIL_STAMPS
-    const double st_point = (double)__builtin_amdgcn_s_memrealtime();
-#endif
-    // every global store of point_block is write-through (st_agent): once this workgroup's stores are acknowledged
-    // (workgroup-scope release = wait for them) the ticket may be taken; no whole-L2 write-back on the hot path
-#ifdef MAGI_FULL_FENCE
-    __threadfence();
-#else
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-#endif
-    __syncthreads();
-    if (tid == 0) s_last = (__hip_atomic_fetch_add(&ch.ticket[chain], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
-    __syncthreads();
-    if (!s_last) return;
-    if (tid == 0) ch.ticket[chain] = 0;
-#ifdef MAGI_FULL_FENCE
-    __threadfence();
-#endif
-    MAGI_STAMP(ch.par + (size_t)chain * PAR_COUNT, 0);
-#ifdef MAGI_TAIL_STAMPS
-    if (tid == 0) { g_stamps[8] = st_entry; g_stamps[9] = st_point; g_stamps[7] = ch.par[(size_t)chain * PAR_COUNT + 40 + 7]; g_stamps[10] = ch.par[(size_t)chain * PAR_COUNT + 40 + 10]; }
-#endif
-    ChainCtl c = s_ctl;
-    const int dim = pb.dim;
-    const int stop_k = min(s_g[0], cfg.total);
-    const int epoch = s_g[1];
-    double* vb = ch.vec + vec_off(pb, chain, 0);
-    double* par = ch.par + (size_t)chain * PAR_COUNT;
-    const TailVecs v = tail_vecs(pb, vb);
-    const size_t sv = pb.dimp;
-
-    bool do_sample = false, do_doubling = false;     // what to set up before returning
-    // The hot path reads of other workgroups' output are the partial sums (ld_agent).  Every other path that reads the
-    // vectors the point workgroups have just written (V_G, V_PLEAF, V_RHOSUB, checkpoints) first invalidates this
-    // XCD's caches; the writers' stores are write-through, so no release fence is needed on their side.
-    bool acquired = false;
-#define TAIL_ACQUIRE() do { if (!acquired) { __threadfence(); acquired = true; } } while (0)
-    const bool hmc = cfg.mode == MAGI_MODE_HMC;       // fixed-L HMC: one forward "subtree" of L leaves, Metropolis at its end
-
-    if (c.phase == PH_IDLE) {
-        if (c.k < stop_k) {
-            do_sample = true;                        // resumed by a later magi_sampler_run
-        } else {
-            if (c.done_epoch != epoch) {
-                c.done_epoch = epoch;
-                if (tid == 0) {
-                    ch.ctl[chain] = c;
-                    const int done = atomicAdd(&ch.gctl->done_chains, 1) + 1;
-                    if (done >= ch.gctl->n_chains) ch.gctl->all_done = 1;
-                }
-            }
-            return;
-        }
-    } else {
-        const LeafPlan lp = ch.plan[chain];          // what k_leap_* just executed for this chain
-        const bool leaf = lp.leaf != 0;
-        MAGI_STAMP(par, 1);
-        // (the leaf's two uniform draws were made by k_leap_*'s service block: par[PAR_ULEAF / PAR_UMERGE])
-        const double u_leaf = par[PAR_ULEAF], u_merge = par[PAR_UMERGE];
-        if (!leaf && tid == 64) shs[16] = cfg.anneal ? temperature(0, cfg.min_temp) : 1.0;
-        // ---- add the streaming kernel's partial sums, finish the parameter entries -----------------------
-        const ReduceOut ro = leap_reduce<DRIFT>(pb, ch, chain, vb, par, lp, sh, shs);
-        MAGI_STAMP(par, 4);
-        const double L = ro.L;
-        double* qcur = vb + (size_t)(V_Q + lp.cur) * sv;      // the state that was evaluated
-        double* pleaf = vb + (size_t)V_PLEAF * sv;
-
-        if (!leaf) {
-            // bootstrap_results: target / gradient at the initial state, cached at beta_temp(0)
-            TAIL_ACQUIRE();
-            for (int e = tid; e < dim; e += blockDim.x) { v.candq[e] = qcur[e]; v.candg[e] = v.g[e]; }
-            c.cand_L = L;
-            c.beta_cache = shs[16];
-            if (c.k < stop_k) do_sample = true;
-            else c.phase = PH_IDLE;
-        } else {
-            c.L_cur = L;
-            c.total_leapfrogs += 1;
-            const int it = c.it;
-            int nk = 0;
-            if (!hmc && (it & 1) != 0)
-                for (int kk = 1; ((it + 1) & ((1 << kk) - 1)) == 0 && (1 << kk) <= c.nsteps; ++kk) nk = kk;
-            bool no_u = true;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < nk) no_u = no_u && (ro.dA[k] > 0.0) && (ro.dB[k] > 0.0);
-            if (nk >= 5) TAIL_ACQUIRE();
-            for (int kk = 5; kk <= nk; ++kk) {       // one leaf in 32 gets here
-                const int left = it + 1 - (1 << kk);
-                const double* cp = v.ckp + (size_t)__popc((unsigned)left) * sv;
-                const double* cr = v.ckrho + (size_t)__popc((unsigned)left) * sv;
-                double dots[2] = {0.0, 0.0};
-                for (int e = tid; e < dim; e += blockDim.x) {
-                    const double df = v.rhosub[e] - cr[e];
-                    dots[0] = fma(df, cp[e], dots[0]);
-                    dots[1] = fma(df, pleaf[e], dots[1]);
-                }
-                block_sum<2>(dots, sh);
-                no_u = no_u && (dots[0] > 0.0) && (dots[1] > 0.0);
-            }
-
-            // ---- energy, multinomial proposal inside the subtree --------------------------------------
-            double energy = c.beta_k * L - 0.5 * ro.pp;
-            if (isnan(energy)) energy = -INFINITY;
-            const double ediff = energy - c.init_energy;
-            const bool not_divergent = (-ediff < cfg.max_energy_diff);
-            if (tid == 0) shs[18] = logaddexp(c.sub_weight, ediff);
-            if (tid == 192) shs[19] = m_exp(fmin(ediff, 0.0));
-            __syncthreads();
-            MAGI_STAMP(par, 5);
-            const double wsum_leaf = shs[18];
-            const bool accept_leaf = !hmc && (u_leaf <= ediff - wsum_leaf);
-            c.leaf_ctr += 1;
-            if (accept_leaf) { c.sub_L = L; c.sub_energy = energy; }
-            c.sub_weight = wsum_leaf;
-            const bool cont_tree = hmc || (not_divergent && (c.cont != 0));
-            c.cont = (no_u && cont_tree) ? 1 : 0;
-            c.nd = (c.nd && not_divergent) ? 1 : 0;
-            if (cont_tree) c.e_sum_sub += shs[19];
-            c.sub_lf += 1;
-            c.it = it + 1;
-
-            if (c.it < c.nsteps && c.cont) {
-                // ---- the speculative next leaf stands: flip buffers, publish its plan -------------------------
-                if (accept_leaf) {                   // proposal copy (expected O(log n) times per subtree)
-                    TAIL_ACQUIRE();
-                    for (int e = tid; e < dim; e += blockDim.x) { v.subq[e] = qcur[e]; v.subg[e] = v.g[e]; }
-                }
-                c.cur = lp.cur ^ 1;
-                if (tid == 0) {
-                    ch.plan[chain] = make_leaf_plan(c, cfg.seed, hmc);
-                    ch.ctl[chain] = c;
-                }
-                MAGI_STAMP(par, 6);
-                MAGI_STAMP_FLUSH(par);
-                return;
-            }
-
-            // ---- subtree finished: merge into the trajectory (biased progressive sampling); for HMC the
-            //      "subtree" is the whole trajectory and the merge is the Metropolis test on its last state ----
-            TAIL_ACQUIRE();
-            const double tree_weight = c.cont ? c.sub_weight : -INFINITY;
-            if (tid == 0) shs[20] = hmc ? 0.0 : logaddexp(tree_weight, c.cand_weight);
-            const double thresh = hmc ? ediff : tree_weight - c.cand_weight;
-            const bool choose = (u_merge <= thresh) && (hmc ? not_divergent : (c.cont != 0));
-            double* pe = (c.dir > 0) ? v.pR : v.pL;
-            double* qe = (c.dir > 0) ? v.qR : v.qL;
-            double* ge = (c.dir > 0) ? v.gR : v.gL;
-            const double* po_ = (c.dir > 0) ? v.pL : v.pR;    // the other end
-            double dots[2] = {0.0, 0.0};
-            for (int e = tid; e < dim; e += blockDim.x) {
-                const double qv = qcur[e], gv = v.g[e];
-                // the subtree proposal is this leaf if it was just accepted, else what V_SUB holds
-                const double sq = (accept_leaf || hmc) ? qv : v.subq[e], sg = (accept_leaf || hmc) ? gv : v.subg[e];
-                if (choose) { v.candq[e] = sq; v.candg[e] = sg; }
-                const double pn = pleaf[e];
-                pe[e] = pn; qe[e] = qv; ge[e] = gv;
-                const double rr = v.rho[e] + v.rhosub[e];
-                v.rho[e] = rr;
-                dots[0] = fma(rr, po_[e], dots[0]);
-                dots[1] = fma(rr, pn, dots[1]);
-            }
-            block_sum<2>(dots, sh);        // (its barriers publish shs[20])
-            if (hmc) { c.sub_L = L; c.sub_energy = energy; }
-            if (choose) { c.cand_L = c.sub_L; c.cand_energy = c.sub_energy; c.cand_bfac = c.beta_k; c.is_accepted = 1; }
-            c.cand_weight = shs[20];
-            if (c.dir > 0) { c.LR = c.L_cur; c.bfacR = c.beta_k; } else { c.LL = c.L_cur; c.bfacL = c.beta_k; }
-            const bool no_u_traj = (dots[0] > 0.0) && (dots[1] > 0.0);
-            c.e_sum += c.e_sum_sub;
-            c.lf_count += c.sub_lf;
-            c.not_div = c.nd;
-            c.depth += 1;
-            const bool continue_tree = !hmc && (c.cont != 0) && no_u_traj;
-            if (hmc) { c.e_sum = shs[19]; }          // acceptance statistic of HMC: min(1, exp(energy difference))
-            if (c.depth < cfg.max_depth && continue_tree) {
-                do_doubling = true;
-            } else {
-                // ---- transition finished ------------------------------------------------------------------
-                if (tid == 0)
-                    dual_averaging_eval(cfg.target_accept, cfg.n_adapt, c.da_step, c.da_step_size, c.da_error_sum, c.da_log_avg,
-                                        c.da_log_shrink, c.e_sum, hmc ? 1 : c.lf_count, &shs[0]);
-                __syncthreads();
-                const int k = c.k;
-                if (tid == 0) {
-                    const size_t o = (size_t)chain * cfg.total + k;
-                    ch.d_step_size[o] = c.eps;
-                    ch.d_lar[o] = shs[0];
-                    ch.d_target[o] = c.cand_bfac * c.cand_L;
-                    ch.d_energy[o] = c.cand_energy;
-                    ch.d_beta[o] = c.beta_k;
-                    ch.d_leapfrogs[o] = c.lf_count;
-                    ch.d_depth[o] = c.depth;
-                    ch.d_flags[o] = (c.not_div ? 0 : 1) | (continue_tree ? 2 : 0) | (c.is_accepted ? 4 : 0);
-                }
-                if (k >= cfg.burnin) {
-                    double* out = ch.samples + ((size_t)chain * (cfg.total - cfg.burnin) + (k - cfg.burnin)) * pb.dimp;
-                    for (int e = tid; e < dim; e += blockDim.x) out[e] = v.candq[e];
-                }
-                if (c.is_accepted) c.beta_cache = c.beta_k;
-                c.da_step_size = shs[1];
-                c.da_error_sum = shs[2];
-                c.da_log_avg = shs[3];
-                c.da_step += 1;
-                c.k = k + 1;
-                if (c.k >= stop_k) {
-                    c.phase = PH_IDLE;
-                    c.done_epoch = epoch;
-                    if (tid == 0) {
-                        LeafPlan off{};
-                        ch.plan[chain] = off;
-                        ch.ctl[chain] = c;
-                        const int done = atomicAdd(&ch.gctl->done_chains, 1) + 1;
-                        if (done >= ch.gctl->n_chains) ch.gctl->all_done = 1;
-                    }
-                    return;
-                }
-                do_sample = true;
-            }
-        }
-    }
-
-    if (do_sample) {
-        // ---- start transition k: temperature, momentum draw, both ends = current proposal ----------------
-        __syncthreads();
-        if (tid == 0) shs[4] = cfg.anneal ? temperature(c.k, cfg.min_temp) : 1.0;
-        double pp0[1] = {0.0};
-        for (int e = tid; e < dim; e += blockDim.x) {
-            const double z = rng_normal_elem((unsigned)e, (unsigned)c.k, (unsigned)c.chain_id, cfg.seed);
-            pp0[0] = fma(z, z, pp0[0]);
-            v.pL[e] = z; v.pR[e] = z; v.rho[e] = z;
-            const double qq = v.candq[e], gg = v.candg[e];
-            v.qL[e] = qq; v.qR[e] = qq;
-            v.gL[e] = gg; v.gR[e] = gg;
-        }
-        block_sum<1>(pp0, sh);              // (its barriers also publish shs[4])
-        c.beta_k = shs[4];
-        const double bc = cfg.stale ? c.beta_cache : c.beta_k;
-        c.eps = c.da_step_size;
-        c.init_energy = bc * c.cand_L - 0.5 * pp0[0];
-        c.LL = c.LR = c.cand_L;
-        c.bfacL = c.bfacR = bc;
-        c.cand_bfac = bc;
-        c.cand_energy = c.init_energy;
-        c.cand_weight = 0.0;
-        c.e_sum = 0.0;
-        c.lf_count = 0;
-        c.not_div = 1;
-        c.is_accepted = 0;
-        c.depth = 0;
-        c.leaf_ctr = 0;
-        do_doubling = true;
-    }
-
-    if (do_doubling) {
-        // ---- start a doubling from the end selected by the direction bit; first half/full step ----------
-        // (leapfrog with identity mass: p_half = p + eps/2 * grad ; q' = q + eps * p_half)
-        Philox4 r = philox4x32_10((unsigned)c.depth, (unsigned)c.k, (unsigned)c.chain_id, STREAM_DIRECTION, cfg.seed);
-        const bool fwd = hmc || (r.x & 1u) != 0;
-        c.dir = fwd ? 1 : -1;
-        const double* pe = fwd ? v.pR : v.pL;
-        const double* qe = fwd ? v.qR : v.qL;
-        const double* ge = fwd ? v.gR : v.gL;
-        const double bf = fwd ? c.bfacR : c.bfacL;
-        const double eps = c.dir * c.eps;
-        const double hs = 0.5 * eps * bf;
-        c.cur ^= 1;
-        double* qw = vb + (size_t)(V_Q + c.cur) * sv;
-        double* pw = vb + (size_t)(V_P + c.cur) * sv;
-        for (int e = tid; e < dim; e += blockDim.x) {
-            const double ph = pe[e] + hs * ge[e];
-            pw[e] = ph;
-            const double qn = qe[e] + eps * ph;
-            qw[e] = qn;
-            v.rhosub[e] = 0.0;
-            if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par);
-        }
-        c.nsteps = hmc ? cfg.hmc_L : (1 << c.depth);
-        c.it = 0;
-        c.sub_weight = -INFINITY;
-        c.e_sum_sub = 0.0;
-        c.sub_lf = 0;
-        c.cont = 1;
-        c.nd = c.not_div;
-        c.phase = PH_LEAF;
-        if (tid == 0) ch.plan[chain] = make_leaf_plan(c, cfg.seed, hmc);
-    } else if (tid == 0) {
-        LeafPlan off{};                  // idle after the bootstrap gradient
-        ch.plan[chain] = off;
-    }
-    if (tid == 0) ch.ctl[chain] = c;
-}
 
 __global__ void k_init_chains(DevChains ch, SamplerCfgDev cfg, const long long* chain_ids) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -421,9 +16,13 @@ __global__ void k_init_chains(DevChains ch, SamplerCfgDev cfg, const long long* 
     ChainCtl c{};
     c.phase = PH_INIT;
     c.cur = 0;
+    // slot 0: the stream evaluates buffer 0 as is (ring entry 1 = "previous" plan, skip-type), the point phase runs
+    // the bootstrap plan the decisions publish for it (PH_INIT)
     LeafPlan p{};
-    p.active = 1;                      // bootstrap gradient at buffer 0, no leapfrog
-    ch.plan[i] = p;
+    p.active = 1; p.skip = 1; p.cur = 0;
+    ch.plan[(size_t)ch.n_chains + i] = p;
+    LeafPlan off{};
+    ch.plan[i] = off;
     c.chain_id = chain_ids ? chain_ids[i] : (long long)i;
     c.da_step_size = cfg.step_size;
     c.da_log_shrink = log(10.0 * cfg.step_size);
@@ -433,16 +32,6 @@ __global__ void k_init_chains(DevChains ch, SamplerCfgDev cfg, const long long* 
 }
 
 }  // namespace
-
-int magi_launch_tail(magi_handle* h, int n_chains, hipStream_t s) {
-    const dim3 g(h->ch.n_wg, n_chains), b(PT_THREADS);
-#define MAGI_CALL(DR) hipLaunchKernelGGL(k_tail<DR>, g, b, 0, s, h->pb, h->ch, h->cfg)
-    MAGI_DRIFT_DISPATCH(h->pb.drift, MAGI_CALL);
-#undef MAGI_CALL
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("tail launch: ") + hipGetErrorString(e));
-    return MAGI_OK;
-}
 
 int magi_launch_init_chains(magi_handle* h, const long long* d_chain_ids, hipStream_t s) {
     const int n = h->n_chains;

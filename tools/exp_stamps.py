@@ -22,8 +22,7 @@ for rep in range(40):
     rows.append(eng.debug_par(0)[40:56].copy())
 rows = np.array(rows)
 d = lambda a, b: np.median((rows[:, b] - rows[:, a]) * 10.0)
-# stamps: 7 stream block0 start, 10 stream last block start, 8 tail(last wg) entry, 9 after point_block, 0 after acquire fence,
-#         1 plan loaded, 3 partial sums added, 4 reduce done, 5 decision, 6 hot-path end
-print("ns: stream start -> last-block start %.0f | stream start -> tail entry %.0f | point_block %.0f | fences+ticket %.0f | ctl+plan %.0f | "
-      "add partials %.0f | param entries %.0f | decide %.0f | publish %.0f | stream start -> hot end %.0f" %
-      (d(7, 10), d(7, 8), d(8, 9), d(9, 0), d(0, 1), d(1, 3), d(3, 4), d(4, 5), d(5, 6), d(7, 6)))
+# stamps inside the decision workgroup (decide.h): 0 entry (state staged), 1 uniforms issued, 3 partial sums added,
+# 4 reduce done, 5 decision, 6 hot-path end
+print("ns: first round of loads %.0f | ->1 %.0f | add partials %.0f | param entries %.0f | decide %.0f | publish %.0f | total %.0f" %
+      (d(8, 0), d(0, 1), d(1, 3), d(3, 4), d(4, 5), d(5, 6), d(8, 6)))
