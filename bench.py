@@ -40,6 +40,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2, help="oracle NUTS transitions for the CPU baseline")
     ap.add_argument("--seed", type=int, default=20250103)
+    ap.add_argument("--distinct-chains", action="store_true",
+                    help="give every rank its own Philox chain ids (statistically independent chains).  Default: every rank "
+                         "runs the chain ids of the 1-GPU run, so per-GPU work is identical for every N (weak scaling); NUTS "
+                         "trees of independent chains differ by up to 2x in leapfrogs per sample, which a max-over-ranks "
+                         "timer would report as a scaling loss (DESIGN.md section 5)")
     return ap.parse_args()
 
 
@@ -86,7 +91,8 @@ def main():
     cfg = eng.default_cfg(num_results=a.warmup + a.steps, num_burnin_steps=a.burnin, stale_cache=0)
     rep = lambda v: np.repeat(np.asarray(v)[None], cpg, axis=0)
     from magi_v2_amd.shard import chain_ids_for_rank
-    chain_ids = chain_ids_for_rank(rank, world, cpg * world)
+    unit_ids = chain_ids_for_rank(rank, world, cpg * world)              # which (dataset, chain) units this rank owns
+    chain_ids = unit_ids if a.distinct_chains else list(range(cpg))      # the Philox streams they are sampled with
     eng.sampler_init(cfg, rep(Xhat), rep(sig_pre0), rep(th_pre0), seed=a.seed, chain_ids=chain_ids)
     eng.sampler_run(a.burnin)
     if a.warmup > 0:
@@ -116,7 +122,7 @@ def main():
     flat = np.concatenate([Xs.reshape(cpg, Xs.shape[1], -1), sp, tp], axis=2)     # [chains, results, N*D + D + P]
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    allsamp, gids = gather_samples(flat, chain_ids, dst=0)
+    allsamp, gids = gather_samples(flat, unit_ids, dst=0)
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - t1) * 1e3 if world > 1 else 0.0
     th_all = allsamp[:, :, -P:] if rank == 0 else None
@@ -213,7 +219,9 @@ def main():
         "config": {"workload": f"SEIR N={N} x 4 components, {'dense' if band is None else 'band ' + str(band)}, "
                                f"NUTS(max depth 10)+dual averaging+log annealing, {cpg} chain(s)/GPU",
                    "grid": N, "components": D, "thetas": P, "chains_total": n_chains, "bandsize": band,
-                   "burnin_untimed": a.burnin, "parallelism": f"chains x{world}"},
+                   "burnin_untimed": a.burnin, "parallelism": f"chains x{world}",
+                   "chain_streams": "distinct per rank" if a.distinct_chains or world == 1 else
+                                    "every rank samples the 1-GPU run's chain ids (identical per-GPU work)"},
         "roofline": roofline, "cpu_baseline": cpu,
         "leapfrogs_per_s": round(lf_total / elapsed, 1), "us_per_leapfrog_slot": round(elapsed / (lf_total / n_chains) * 1e6, 2),
         "mean_tree_depth": round(float(post.mean()), 2), "device_ms": round(dev_ms, 2), "build_ms": round(build_ms, 1),
