@@ -56,9 +56,17 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
+    # MAGI_BENCH_REHEARSE=1: all ranks share cuda:0 and talk over gloo -- a functional rehearsal of the N > 1 path on a
+    # one-GPU box (timings meaningless); the real run is one rank per GPU over RCCL
+    rehearse = os.environ.get("MAGI_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+    red_dev = "cpu" if rehearse else "cuda"
 
     from magi_v2_amd import host
     from magi_v2_amd.engine import MagiEngine
@@ -76,7 +84,7 @@ def main():
     LB = host.sigma_sqs_lower_bound(Xhat)
     sig_pre0, th_pre0 = host.softplus_inverse_inits(hp["sigma_sqs"], np.ones(P), LB)
 
-    eng = MagiEngine(local_rank)
+    eng = MagiEngine(dev_index)
     t0 = time.perf_counter()
     want_host = (rank == 0 and world == 1 and not a.no_cpu_baseline)
     mats = eng.build_matrices(I, hp["phi1s"], hp["phi2s"], 2.01, bandsize=band, want_host=want_host)
@@ -108,8 +116,8 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    lfs = torch.tensor([float(lf)], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    lfs = torch.tensor([float(lf)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(lfs, op=dist.ReduceOp.SUM)
