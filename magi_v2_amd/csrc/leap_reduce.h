@@ -1,12 +1,12 @@
-// Reduce half of a leapfrog slot, shared by the sampler's tail (k_tail) and by the validation
+// Reduce half of a leapfrog slot, shared by the sampler's decisions (decide.h) and by the validation
 // entry point magi_logpost_grad_fused (k_leap_finalize).
 //
-// k_leap_* (leap.hip) has already, on all CUs: applied the four single-phase operators, assembled
-// dL/dX, completed the momentum step of the X entries, extended the subtree momentum sum, written
-// the U-turn checkpoint, accumulated the checkpointed U-turn dot products and written the
-// speculative next position -- and left PART_K partial sums per workgroup.  What remains is O(#WG):
-// add the partials, finish the D + P parameter entries (whose gradients are global sums), and hand
-// the totals to the caller's decision logic.
+// k_stream + k_point (leap.hip, leap_point.h) have already, on all CUs: applied the four single-phase operators,
+// assembled dL/dX, completed the momentum step of the X entries, extended the subtree momentum sum, written
+// the U-turn checkpoint, accumulated the checkpointed U-turn dot products and written the speculative next
+// position -- and left PART_K partial sums per point workgroup.  What remains is O(#WG): add the partials,
+// finish the D + P parameter entries (whose gradients are global sums), and hand the totals to the caller's
+// decision logic.
 //
 // PART layout: [0] t12  [1..4] ss_d  [5..10] tp_p  [11] p.p  [12+2k, 13+2k] U-turn dots of check k
 #pragma once

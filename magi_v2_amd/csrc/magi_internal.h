@@ -250,7 +250,7 @@ __device__ inline double rng_normal_elem(unsigned int e, unsigned int step, unsi
 // epilogues and out of the 1024-thread reduce is worth tens of microseconds per gradient).
 // ------------------------------------------------------------------------------------------
 enum ParOff { PAR_TH = 0, PAR_SGT = 8, PAR_LJT = 16, PAR_SIG2 = 24, PAR_SGS = 28, PAR_LJS = 32, PAR_LOG2PIS = 36,
-              PAR_ULEAF = 56, PAR_UMERGE = 57 /* log1p(-U) draws of the leaf in flight, made by k_leap_*'s service block */,
+              PAR_ULEAF = 56, PAR_UMERGE = 57 /* (unused) */,
               PAR_COUNT = 64 };
 
 // entry j of the parameter block: j < D -> sigma_pre[j], else theta_pre[j - D]
