@@ -269,39 +269,142 @@ __global__ __launch_bounds__(256) void k_gemm_f64(GemmArgs g) {
 }
 
 // =============================================================================================
-// diagonal block: Cholesky of an n x n (n <= 128) SPD block + explicit inverse of its factor.
-// Packed lower-triangular storage in LDS: 2 x 66 KB.
+// diagonal block: Cholesky of an n x n (n <= 128) SPD block + explicit inverse of its factor, one workgroup.
+//
+// A column-by-column factorisation in LDS is a chain of 128 x 3 barriers (measured 0.48 ms per block, a quarter of the
+// N = 8192 build).  Here the block is processed in four 32-wide sub-blocks:
+//   1. ONE wave factorises the 32 x 32 diagonal sub-block with a row per lane in registers -- pivots and multipliers
+//      travel by v_readlane, no barrier, no LDS -- and inverts the factor the same way (a column per lane);
+//   2. the rows below are multiplied by that inverse (one thread per row, operands broadcast from LDS);
+//   3. the trailing sub-matrix takes its rank-32 update in 2 x 2 register tiles;
+// then the off-diagonal blocks of the inverse follow from 32 x 32 x 32 products (block forward substitution).
+// LDS: one 128 x 129 array holds L in its lower triangle and the strict part of Linv, transposed, in its upper
+// triangle; the diagonal of Linv and one 32 x 33 temporary sit behind it.  The block is padded to 128 with the
+// identity so no loop carries bounds.
 // =============================================================================================
-__device__ inline int tri(int i, int j) { return ((i * (i + 1)) >> 1) + j; }
+constexpr int DG_LD = 129;
+constexpr int DG_LDS_DOUBLES = 128 * DG_LD + 128 + 32 * 33 + 2;
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// C (32 x 32, thread tile 2 x 2) = sum over k of  a(i, k) * b(k, j)  with accessors (no bounds: the caller passes K)
+template <class FA, class FB>
+__device__ __forceinline__ void dg_tile_gemm(int K, FA a, FB b, double (&c)[2][2]) {
+    const int ti = (threadIdx.x >> 4) * 2, tj = (threadIdx.x & 15) * 2;
+    c[0][0] = c[0][1] = c[1][0] = c[1][1] = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const double a0 = a(ti, k), a1 = a(ti + 1, k), b0 = b(k, tj), b1 = b(k, tj + 1);
+        c[0][0] = fma(a0, b0, c[0][0]); c[0][1] = fma(a0, b1, c[0][1]);
+        c[1][0] = fma(a1, b0, c[1][0]); c[1][1] = fma(a1, b1, c[1][1]);
+    }
+}
 
 __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int n, double* Linv /* [128][128] */, int* status, int block_row0) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* L = lds;                       // packed lower, 128*129/2
-    double* X = lds + 128 * 129 / 2;       // packed lower inverse
-    int& bad = *reinterpret_cast<int*>(lds + 2 * (128 * 129 / 2));   // keeps the LDS carve-out aligned
-    const int tid = threadIdx.x;
+    double* S = lds;                               // [128][DG_LD]
+    double* dinv = lds + 128 * DG_LD;              // diagonal of the inverse
+    double* T = dinv + 128;                        // [32][33]
+    int& bad = *reinterpret_cast<int*>(T + 32 * 33);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) bad = -1;
-    for (int e = tid; e < n * n; e += 256) {
-        const int i = e / n, j = e - i * n;
-        if (j <= i) L[tri(i, j)] = A[(long)i * lda + j];
+    for (int e = tid; e < 128 * 128; e += 256) {
+        const int i = e >> 7, j = e & 127;
+        double v = (i == j) ? 1.0 : 0.0;           // identity padding
+        if (i < n && j < n) v = (j <= i) ? A[(long)i * lda + j] : 0.0;
+        S[i * DG_LD + j] = v;
     }
     __syncthreads();
-    const int tx = tid & 15, ty = tid >> 4;
-    for (int k = 0; k < n; ++k) {
-        const double akk = L[tri(k, k)];
-        if (!(akk > 0.0)) {                // also catches NaN
-            if (tid == 0) { bad = k; }
-            __syncthreads();
-            break;
+
+    for (int kb = 0; kb < 4; ++kb) {
+        const int c0 = 32 * kb;
+        // ---- 1. diagonal sub-block: factor + inverse in the registers of wave 0 (lane = row, then lane = column) ----
+        if (wave == 0) {
+            const int r = lane & 31;
+            double d[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) d[c] = S[(c0 + r) * DG_LD + c0 + c];          // (upper part holds zeros / inverse: masked below)
+#pragma unroll
+            for (int c = 0; c < 32; ++c) if (c > r) d[c] = 0.0;
+            int fail = -1;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const double piv = readlane_f64(d[k], k);
+                if (!(piv > 0.0) && fail < 0) fail = c0 + k;                              // uniform; also catches NaN
+                const double dk = sqrt(piv);
+                d[k] = (r == k) ? dk : d[k] / dk;
+#pragma unroll
+                for (int j = k + 1; j < 32; ++j) {
+                    const double ljk = readlane_f64(d[k], j);
+                    if (r >= j) d[j] = fma(-d[k], ljk, d[j]);
+                }
+            }
+            if (fail >= 0 && lane == 0) bad = fail;
+            // inverse: lane j holds column j of inv(L11)
+            double x[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int k = 0; k < i; ++k) sacc = fma(readlane_f64(d[k], i), x[k], sacc);
+                const double lii = readlane_f64(d[i], i);
+                x[i] = (i < r) ? 0.0 : ((i == r) ? 1.0 : -sacc) / lii;
+            }
+            if (lane < 32) {
+#pragma unroll
+                for (int c = 0; c < 32; ++c) {
+                    if (c <= r) S[(c0 + r) * DG_LD + c0 + c] = d[c];                      // L11
+                    if (c > r) S[(c0 + r) * DG_LD + c0 + c] = x[c];                       // inv(L11)[c][r], stored transposed
+                }
+                double xr = 0.0;
+#pragma unroll
+                for (int c = 0; c < 32; ++c) if (c == r) xr = x[c];           // (a runtime index would put x[] in scratch)
+                dinv[c0 + r] = xr;
+            }
         }
-        const double dk = sqrt(akk);
         __syncthreads();
-        for (int i = k + tid; i < n; i += 256) L[tri(i, k)] = (i == k) ? dk : L[tri(i, k)] / dk;
+        if (bad >= 0) break;
+        if (kb == 3) break;
+        // ---- 2. rows below: L21 = A21 * inv(L11)^T, one thread per row ------------------------------------------------
+        {
+            const int i = c0 + 32 + tid;
+            if (i < 128) {
+                double a[32], o[32];
+#pragma unroll
+                for (int k = 0; k < 32; ++k) a[k] = S[i * DG_LD + c0 + k];
+#pragma unroll
+                for (int c = 0; c < 32; ++c) {
+                    double acc = a[c] * dinv[c0 + c];
+#pragma unroll
+                    for (int k = 0; k < c; ++k) acc = fma(a[k], S[(c0 + k) * DG_LD + c0 + c], acc);     // inv(L11)[c][k]
+                    o[c] = acc;
+                }
+#pragma unroll
+                for (int c = 0; c < 32; ++c) S[i * DG_LD + c0 + c] = o[c];
+            }
+        }
         __syncthreads();
-        for (int i = k + 1 + ty; i < n; i += 16) {
-            const double lik = L[tri(i, k)];
-#pragma unroll 4
-            for (int j = k + 1 + tx; j <= i; j += 16) L[tri(i, j)] -= lik * L[tri(j, k)];
+        // ---- 3. trailing update A22 -= L21 L21^T on the lower triangle, 2 x 2 tiles ------------------------------------------
+        {
+            const int m0 = c0 + 32, mt = (128 - m0) >> 1;           // tiles per side
+            for (int t = tid; t < mt * mt; t += 256) {
+                const int bi = t / mt, bj = t - bi * mt;
+                if (bj > bi) continue;
+                const int i = m0 + 2 * bi, j = m0 + 2 * bj;
+                double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
+#pragma unroll 8
+                for (int k = 0; k < 32; ++k) {
+                    const double a0 = S[i * DG_LD + c0 + k], a1 = S[(i + 1) * DG_LD + c0 + k];
+                    const double b0 = S[j * DG_LD + c0 + k], b1 = S[(j + 1) * DG_LD + c0 + k];
+                    c00 = fma(a0, b0, c00); c01 = fma(a0, b1, c01); c10 = fma(a1, b0, c10); c11 = fma(a1, b1, c11);
+                }
+                S[i * DG_LD + j] -= c00;
+                S[(i + 1) * DG_LD + j] -= c10;
+                S[(i + 1) * DG_LD + j + 1] -= c11;
+                if (bj < bi) S[i * DG_LD + j + 1] -= c01;           // (on the diagonal tile that entry is in the upper triangle)
+            }
         }
         __syncthreads();
     }
@@ -309,38 +412,34 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
         if (tid == 0) atomicCAS(status, -1, block_row0 + bad);
         return;
     }
-    // inverse by forward substitution: columns are independent; two adjacent lanes share a column and
-    // split the inner sum (even / odd k), combined with one DPP-free shuffle
-    {
-        const int j = tid >> 1, half = tid & 1;
-        if (j < n && half == 0) X[tri(j, j)] = 1.0 / L[tri(j, j)];
-        for (int i = 1; i < n; ++i) {
-            const int ro = (i * (i + 1)) >> 1;
-            double s = 0.0;
-            if (j < i && j < n) {
-                double s1 = 0.0;
-#pragma unroll 4
-                for (int k = j + half; k < i; k += 4) {
-                    s = fma(L[ro + k], X[tri(k, j)], s);
-                    if (k + 2 < i) s1 = fma(L[ro + k + 2], X[tri(k + 2, j)], s1);
-                }
-                s += s1;
-            }
-            s += __shfl_xor(s, 1, 64);
-            if (j < i && j < n && half == 0) X[ro + j] = -s / L[ro + i];
-            // the next row reads X[i][j] written by the partner lane of the same wave only -> wave-level order suffices,
-            // but columns of different waves never interact, so no block barrier is needed
-            __builtin_amdgcn_wave_barrier();
+    // ---- off-diagonal blocks of the inverse: X_ij = -X_ii * sum_{k=j}^{i-1} L_ik X_kj  (block rows in order) -----------------------
+    auto Xf = [&](int i, int j) -> double { return i == j ? dinv[i] : (i > j ? S[j * DG_LD + i] : 0.0); };
+    for (int bi = 1; bi < 4; ++bi)
+        for (int bj = 0; bj < bi; ++bj) {
+            double c[2][2];
+            dg_tile_gemm((bi - bj) * 32,
+                         [&](int i, int k) { return S[(32 * bi + i) * DG_LD + 32 * bj + k]; },
+                         [&](int k, int j) { return Xf(32 * bj + k, 32 * bj + j); }, c);
+            const int ti = (tid >> 4) * 2, tj = (tid & 15) * 2;
+            T[ti * 33 + tj] = c[0][0]; T[ti * 33 + tj + 1] = c[0][1]; T[(ti + 1) * 33 + tj] = c[1][0]; T[(ti + 1) * 33 + tj + 1] = c[1][1];
+            __syncthreads();
+            dg_tile_gemm(32,
+                         [&](int i, int k) { return Xf(32 * bi + i, 32 * bi + k); },
+                         [&](int k, int j) { return T[k * 33 + j]; }, c);
+            __syncthreads();                       // every thread is done with T and with the X blocks it read
+            S[(32 * bj + tj) * DG_LD + 32 * bi + ti] = -c[0][0];
+            S[(32 * bj + tj + 1) * DG_LD + 32 * bi + ti] = -c[0][1];
+            S[(32 * bj + tj) * DG_LD + 32 * bi + ti + 1] = -c[1][0];
+            S[(32 * bj + tj + 1) * DG_LD + 32 * bi + ti + 1] = -c[1][1];
+            __syncthreads();
         }
-    }
-    __syncthreads();
     for (int e = tid; e < n * n; e += 256) {
         const int i = e / n, j = e - i * n;
-        A[(long)i * lda + j] = (j <= i) ? L[tri(i, j)] : 0.0;
+        A[(long)i * lda + j] = (j <= i) ? S[i * DG_LD + j] : 0.0;
     }
     for (int e = tid; e < 128 * 128; e += 256) {
         const int i = e >> 7, j = e & 127;
-        Linv[e] = (i < n && j <= i) ? X[tri(i, j)] : 0.0;
+        Linv[e] = (i < n && j <= i) ? (i == j ? dinv[i] : S[j * DG_LD + i]) : 0.0;
     }
 }
 
@@ -491,7 +590,7 @@ int potrf(Linalg& la, double* A, const char* what) {
     int neg1 = -1;
     MAGI_HIP_CHECK(h, hipMemcpyAsync(la.status, &neg1, sizeof(int), hipMemcpyHostToDevice, la.s));
     MAGI_HIP_CHECK(h, hipStreamSynchronize(la.s));
-    const size_t lds = (size_t)(2 * (128 * 129 / 2) + 2) * sizeof(double);
+    const size_t lds = (size_t)DG_LDS_DOUBLES * sizeof(double);
     for (int j0 = 0, jb = 0; j0 < N; j0 += NB, ++jb) {
         const int n = std::min(NB, N - j0);
         double* Ajj = A + (size_t)j0 * N + j0;
@@ -594,7 +693,7 @@ int linalg_init(Linalg& la, magi_handle* h, int N) {
     MAGI_HIP_CHECK(h, hipMalloc(&la.dinv, (size_t)nb * 128 * 128 * sizeof(double)));
     MAGI_HIP_CHECK(h, hipMalloc(&la.panel, std::max((size_t)N * 128, (size_t)N * N / 2 + 128 * 128) * sizeof(double)));
     MAGI_HIP_CHECK(h, hipMalloc(&la.status, sizeof(int)));
-    MAGI_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_diag_chol_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (128 * 129 / 2) + 2) * (int)sizeof(double)));
+    MAGI_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_diag_chol_inv), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS_DOUBLES * (int)sizeof(double)));
     return MAGI_OK;
 }
 
