@@ -584,12 +584,21 @@ int launch_gemm(magi_handle* h, hipStream_t s, const GemmArgs& g, int batch = 1,
 
 // In-place lower Cholesky of A (N x N row-major, ld = N), right-looking, NB = 128.  The inverses
 // of the diagonal blocks are kept in la.dinv for the triangular inverse that follows.
-int potrf(Linalg& la, double* A, const char* what) {
+int potrf_status(Linalg& la, const char* what) {
+    magi_handle* h = la.h;
+    int st = -1;
+    MAGI_HIP_CHECK(h, hipMemcpyAsync(&st, la.status, sizeof(int), hipMemcpyDeviceToHost, la.s));
+    MAGI_HIP_CHECK(h, hipStreamSynchronize(la.s));
+    if (st >= 0)
+        return magi_fail(h, MAGI_E_NOTSPD, std::string("Cholesky of ") + what + ": non-positive pivot at index " + std::to_string(st));
+    return MAGI_OK;
+}
+
+// defer_status: only enqueue (no host synchronisation); the caller asks potrf_status later
+int potrf(Linalg& la, double* A, const char* what, bool defer_status = false) {
     magi_handle* h = la.h;
     const int N = la.N, NB = 128;
-    int neg1 = -1;
-    MAGI_HIP_CHECK(h, hipMemcpyAsync(la.status, &neg1, sizeof(int), hipMemcpyHostToDevice, la.s));
-    MAGI_HIP_CHECK(h, hipStreamSynchronize(la.s));
+    MAGI_HIP_CHECK(h, hipMemsetAsync(la.status, 0xFF, sizeof(int), la.s));          // -1
     const size_t lds = (size_t)DG_LDS_DOUBLES * sizeof(double);
     for (int j0 = 0, jb = 0; j0 < N; j0 += NB, ++jb) {
         const int n = std::min(NB, N - j0);
@@ -615,12 +624,7 @@ int potrf(Linalg& la, double* A, const char* what) {
         t.lower_only = 1;
         if ((rc = launch_gemm(h, la.s, t, 1, BC_TRAIL))) return rc;
     }
-    int st = -1;
-    MAGI_HIP_CHECK(h, hipMemcpyAsync(&st, la.status, sizeof(int), hipMemcpyDeviceToHost, la.s));
-    MAGI_HIP_CHECK(h, hipStreamSynchronize(la.s));
-    if (st >= 0)
-        return magi_fail(h, MAGI_E_NOTSPD, std::string("Cholesky of ") + what + ": non-positive pivot at index " + std::to_string(st));
-    return MAGI_OK;
+    return defer_status ? MAGI_OK : potrf_status(la, what);
 }
 
 // In-place T = L^-1 (lower) from the factor left by potrf, bottom-up over block sizes s = 128, 256, ...:
@@ -751,32 +755,54 @@ struct DevBuf {
 // One evaluation of the GP marginal log likelihood of component data x (mean mu) and its gradient with
 // respect to (phi1, phi2, sigma^2):  S = phi1 R(phi2) + (sigma^2 + jitter) I
 //   ll = -1/2 r^T S^-1 r - 1/2 log|S| - N/2 log 2pi ,  d ll/d. = 1/2 tr((a a^T - S^-1) dS/d.) , a = S^-1 r
-struct FitWork {
+struct FitWork {          // one component: its own work space and stream, so the D independent fits overlap on the GPU
     DevBuf I, r, Kap, pK, Kpp, S, Sinv, alpha, part, out;
-    Linalg la;
+    Linalg la{};
+    double* host = nullptr;          // pinned: 6 outputs
+    int* host_status = nullptr;      // pinned
+    hipStream_t stream = nullptr;
     int N = 0, nblk = 0;
 };
 
-int fit_eval(magi_handle* h, FitWork& w, double phi1, double phi2, double sig2, double nu, double jitter, double* ll, double* g3) {
+// enqueue one evaluation of component `w` on ITS stream (w.la.s); nothing here waits for the device
+int fit_issue(magi_handle* h, FitWork& w, double phi1, double phi2, double sig2, double nu, double jitter) {
     const int N = w.N;
+    hipStream_t keep = h->stream;
+    h->stream = w.la.s;                       // the helpers below launch on the handle's stream
     int rc = launch_matern(h, w.I.p, N, phi1, phi2, nu, w.Kap.p, w.pK.p, w.Kpp.p);
-    if (rc) return rc;
     const size_t nn = (size_t)N * N;
-    hipLaunchKernelGGL(k_fit_shift, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, w.Kap.p, w.S.p, N, sig2 + jitter);
-    if ((rc = potrf(w.la, w.S.p, "GP marginal covariance"))) return rc;
-    hipLaunchKernelGGL(k_fit_logdiag, dim3(1), dim3(256), 0, h->stream, w.S.p, N, w.out.p + 5);
-    if ((rc = trtri(w.la, w.S.p))) return rc;
-    if ((rc = lauum_tt(w.la, w.S.p, w.Sinv.p))) return rc;
-    hipLaunchKernelGGL(k_fit_gemv, dim3((N + 3) / 4), dim3(256), 0, h->stream, w.Sinv.p, w.r.p, w.alpha.p, N);
-    hipLaunchKernelGGL(k_fit_terms, dim3(w.nblk), dim3(256), 0, h->stream, w.Kap.p, w.pK.p, w.Sinv.p, w.alpha.p, w.r.p, w.I.p, N, w.part.p);
-    hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(256), 0, h->stream, w.part.p, w.nblk, w.out.p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("fit launch: ") + hipGetErrorString(e));
-    double o[6];
-    MAGI_HIP_CHECK(h, hipMemcpyAsync(o, w.out.p, sizeof(o), hipMemcpyDeviceToHost, h->stream));
-    MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    if (rc == MAGI_OK) {
+        hipLaunchKernelGGL(k_fit_shift, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, w.Kap.p, w.S.p, N, sig2 + jitter);
+        rc = potrf(w.la, w.S.p, "GP marginal covariance", true);
+    }
+    if (rc == MAGI_OK) {
+        hipLaunchKernelGGL(k_fit_logdiag, dim3(1), dim3(256), 0, h->stream, w.S.p, N, w.out.p + 5);
+        rc = trtri(w.la, w.S.p);
+    }
+    if (rc == MAGI_OK) rc = lauum_tt(w.la, w.S.p, w.Sinv.p);
+    if (rc == MAGI_OK) {
+        hipLaunchKernelGGL(k_fit_gemv, dim3((N + 3) / 4), dim3(256), 0, h->stream, w.Sinv.p, w.r.p, w.alpha.p, N);
+        hipLaunchKernelGGL(k_fit_terms, dim3(w.nblk), dim3(256), 0, h->stream, w.Kap.p, w.pK.p, w.Sinv.p, w.alpha.p, w.r.p, w.I.p, N, w.part.p);
+        hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(256), 0, h->stream, w.part.p, w.nblk, w.out.p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = magi_fail(h, MAGI_E_HIP, std::string("fit launch: ") + hipGetErrorString(e));
+    }
+    if (rc == MAGI_OK) {
+        hipError_t e = hipMemcpyAsync(w.host, w.out.p, 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(w.host_status, w.la.status, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+        if (e != hipSuccess) rc = magi_fail(h, MAGI_E_HIP, std::string("fit readback: ") + hipGetErrorString(e));
+    }
+    h->stream = keep;
+    return rc;
+}
+
+int fit_finish(magi_handle* h, FitWork& w, double phi1, double phi2, double* ll, double* g3) {
+    MAGI_HIP_CHECK(h, hipStreamSynchronize(w.la.s));
+    if (*w.host_status >= 0)
+        return magi_fail(h, MAGI_E_NOTSPD, "Cholesky of GP marginal covariance: non-positive pivot at index " + std::to_string(*w.host_status));
+    const double* o = w.host;
     const double logdet = 2.0 * o[5];
-    *ll = -0.5 * o[3] - 0.5 * logdet - 0.5 * N * std::log(2.0 * 3.141592653589793);
+    *ll = -0.5 * o[3] - 0.5 * logdet - 0.5 * w.N * std::log(2.0 * 3.141592653589793);
     g3[0] = 0.5 * o[0] / phi1;
     g3[1] = 0.5 * o[1] / phi2;
     g3[2] = 0.5 * (o[4] - o[2]);
@@ -808,27 +834,37 @@ int magi_fused_operators(magi_handle* h, int N, int D, double* dCs_inout_H, cons
 int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const double* X /* [N][D] */, const double* mu,
                             const double* mu_phi2, const double* sd_phi2, const double* sig_loc, double nu, int iters, double lr,
                             double jitter, double* phi1, double* phi2, double* sig2, double* loss_trace) {
-    FitWork w;
-    w.N = N;
-    w.nblk = (N + 3) / 4;
+    std::vector<FitWork> ws(D);
     const size_t nn = (size_t)N * N;
-    MAGI_HIP_CHECK(h, w.I.alloc(N));
-    MAGI_HIP_CHECK(h, w.r.alloc((size_t)N * D));
-    MAGI_HIP_CHECK(h, w.Kap.alloc(nn));
-    MAGI_HIP_CHECK(h, w.pK.alloc(nn));
-    MAGI_HIP_CHECK(h, w.Kpp.alloc(nn));
-    MAGI_HIP_CHECK(h, w.S.alloc(nn));
-    MAGI_HIP_CHECK(h, w.Sinv.alloc(nn));
-    MAGI_HIP_CHECK(h, w.alpha.alloc(N));
-    MAGI_HIP_CHECK(h, w.part.alloc((size_t)w.nblk * 5));
-    MAGI_HIP_CHECK(h, w.out.alloc(8));
-    MAGI_HIP_CHECK(h, hipMemcpy(w.I.p, I, sizeof(double) * N, hipMemcpyHostToDevice));
-    std::vector<double> r((size_t)N * D);
-    for (int d = 0; d < D; ++d)
-        for (int i = 0; i < N; ++i) r[(size_t)d * N + i] = X[(size_t)i * D + d] - mu[d];
-    MAGI_HIP_CHECK(h, hipMemcpy(w.r.p, r.data(), sizeof(double) * N * D, hipMemcpyHostToDevice));
-    int rc = linalg_init(w.la, h, N);
-    if (rc) { linalg_free(w.la); return rc; }
+    int rc = MAGI_OK;
+    auto cleanup = [&]() {
+        for (auto& w : ws) {
+            linalg_free(w.la);
+            if (w.host) (void)hipHostFree(w.host);
+            if (w.host_status) (void)hipHostFree(w.host_status);
+            if (w.stream) (void)hipStreamDestroy(w.stream);
+        }
+    };
+    for (int d = 0; d < D && rc == MAGI_OK; ++d) {
+        FitWork& w = ws[d];
+        w.N = N;
+        w.nblk = (N + 3) / 4;
+        hipError_t e = hipSuccess;
+        auto chk = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+        chk(w.I.alloc(N)); chk(w.r.alloc(N)); chk(w.Kap.alloc(nn)); chk(w.pK.alloc(nn)); chk(w.Kpp.alloc(nn)); chk(w.S.alloc(nn));
+        chk(w.Sinv.alloc(nn)); chk(w.alpha.alloc(N)); chk(w.part.alloc((size_t)w.nblk * 5)); chk(w.out.alloc(8));
+        chk(hipHostMalloc(reinterpret_cast<void**>(&w.host), 8 * sizeof(double)));
+        chk(hipHostMalloc(reinterpret_cast<void**>(&w.host_status), sizeof(int)));
+        chk(hipStreamCreate(&w.stream));
+        if (e == hipSuccess) chk(hipMemcpy(w.I.p, I, sizeof(double) * N, hipMemcpyHostToDevice));
+        std::vector<double> r((size_t)N);
+        for (int i = 0; i < N; ++i) r[i] = X[(size_t)i * D + d] - mu[d];
+        if (e == hipSuccess) chk(hipMemcpy(w.r.p, r.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+        if (e != hipSuccess) { rc = magi_fail(h, MAGI_E_HIP, std::string("fit setup: ") + hipGetErrorString(e)); break; }
+        rc = linalg_init(w.la, h, N);
+        w.la.s = w.stream;
+    }
+    if (rc) { cleanup(); return rc; }
 
     auto softplus = [](double x) { return std::log1p(std::exp(x)); };
     auto softplus_inv = [](double y) { return std::log(std::expm1(y)); };
@@ -838,15 +874,17 @@ int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const
     for (int d = 0; d < D; ++d) { raw[d] = softplus_inv(phi1[d]); raw[D + d] = softplus_inv(phi2[d]); raw[2 * D + d] = softplus_inv(sig2[d]); }
     const double sD = std::sqrt((double)D);
     const double b1 = 0.9, b2 = 0.999, eps = 1e-7;
-    double* const rbase = w.r.p;
+    std::vector<double> pv(3 * D);
     for (int t = 1; t <= iters && rc == MAGI_OK; ++t) {
         double loss = 0.0;
+        for (int d = 0; d < D && rc == MAGI_OK; ++d) {             // enqueue all components, then collect
+            pv[d] = softplus(raw[d]); pv[D + d] = softplus(raw[D + d]); pv[2 * D + d] = softplus(raw[2 * D + d]);
+            rc = fit_issue(h, ws[d], pv[d], pv[D + d], pv[2 * D + d], nu, jitter);
+        }
         for (int d = 0; d < D && rc == MAGI_OK; ++d) {
-            const double p1 = softplus(raw[d]), p2 = softplus(raw[D + d]), s2 = softplus(raw[2 * D + d]);
+            const double p1 = pv[d], p2 = pv[D + d], s2 = pv[2 * D + d];
             double ll, g3[3];
-            w.r.p = rbase + (size_t)d * N;
-            rc = fit_eval(h, w, p1, p2, s2, nu, jitter, &ll, g3);
-            w.r.p = rbase;
+            rc = fit_finish(h, ws[d], p1, p2, &ll, g3);
             if (rc) break;
             // TruncatedNormal(loc, scale, low = 1e-6) priors: only the quadratic depends on the value (magi_v2.py:611-627)
             const double sc1 = 1000.0 * sD, sc2 = sd_phi2[d] * sD, sc3 = 1000.0 * sD;
@@ -866,8 +904,8 @@ int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const
             raw[k] -= a * m[k] / (std::sqrt(v[k]) + eps);
         }
     }
-    w.r.p = rbase;
-    linalg_free(w.la);
+    for (auto& w : ws) (void)hipStreamSynchronize(w.stream);
+    cleanup();
     if (rc) return rc;
     for (int d = 0; d < D; ++d) { phi1[d] = softplus(raw[d]); phi2[d] = softplus(raw[D + d]); sig2[d] = softplus(raw[2 * D + d]); }
     return MAGI_OK;
