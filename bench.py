@@ -218,6 +218,14 @@ def main():
                "sample": f"{a.cpu_steps} NUTS transitions ({n_lf} leapfrogs) of the same chain continued from the GPU state by "
                          "oracle/magi_oracle.py (numpy + OpenBLAS restatement of magi_v2.py:308-348 and TFP NUTS)",
                "leapfrogs_per_s": round(n_lf / cpu_s, 2), "host_cpus": os.cpu_count()}
+        # the same gradient on ONE host thread (SURVEY 8d asks for both): 40 evaluations, scaled by the leapfrogs per sample above
+        with threadpoolctl.threadpool_limits(limits=1):
+            fn_L(q)
+            t1 = time.perf_counter()
+            for _ in range(40):
+                fn_L(q)
+            g1 = 40.0 / (time.perf_counter() - t1)
+        cpu["single_thread"] = {"leapfrogs_per_s": round(g1, 2), "samples_per_s": round(g1 / (n_lf / a.cpu_steps), 5)}
 
     out = {
         "metric": "HMC samples/sec (whole node) on SEIR, N grid pts x D comps",
