@@ -31,7 +31,7 @@ def _synthetic_engine(N, band=None):
     return eng, I, hp, Xhat, sp, tp
 
 
-@pytest.mark.parametrize("N,band", [(1024, None), (1024, 80), (4096, None)])
+@pytest.mark.parametrize("N,band", [(1024, None), (1024, 80), (4096, None), (8192, None)])
 def test_full_size_logpost_consistency_and_gradient(N, band):
     eng, I, hp, Xhat, sp, tp = _synthetic_engine(N, band)
     rng = np.random.default_rng(N)
@@ -52,6 +52,21 @@ def test_full_size_logpost_consistency_and_gradient(N, band):
         fd = (lp_p - lp_m) / (2 * h)
         an = (gX * vX).sum() + gs @ vs + gt @ vt
         assert abs(fd - an) <= 1e-4 * max(abs(an), abs(fd)) + 1e-6, (fd, an)     # FD truncation (h^2 term) dominates at large N
+    eng.close()
+
+
+def test_config5_sampler_runs_at_n8192():
+    """BASELINE config 5 (N = 8192 x 4, one chain): the block-streaming sampler on 33 024 operator blocks (4.4 GB) -- a few
+    NUTS transitions stay finite, move the state and take leapfrogs; the fixed-L mode does the same work per leapfrog."""
+    eng, I, hp, Xhat, sp, tp = _synthetic_engine(8192, None)
+    sp0, tp0 = host.softplus_inverse_inits(hp["sigma_sqs"], np.ones(3), host.sigma_sqs_lower_bound(Xhat))
+    cfg = eng.default_cfg(num_results=2, num_burnin_steps=6, stale_cache=0)
+    eng.sampler_init(cfg, Xhat, sp0, tp0, seed=3)
+    lf, ms = eng.sampler_run(8)
+    Xs, s_, t_ = eng.sampler_samples()
+    d = eng.sampler_diag()
+    assert lf == d.leapfrogs_taken.sum() and lf >= 8
+    assert np.isfinite(Xs).all() and np.isfinite(t_).all() and np.abs(Xs[0, -1] - Xhat).max() > 0
     eng.close()
 
 
