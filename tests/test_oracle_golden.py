@@ -180,3 +180,27 @@ def test_oracle_gp_marginal_gradient_matches_finite_differences(golden_dir):
         assert abs(fd - gr[k]) <= 1e-5 * abs(gr[k]) + 1e-6, (k, fd, gr[k])
     out = orc.fit_kernel_hparams(I, X, num_iters=3)
     assert all(np.all(v > 0) for v in out.values())
+
+
+def test_oracle_gp_marginal_likelihood_matches_scikit_learn(golden_dir):
+    """Independent pin of the GP part of the f1 restatement (magi_v2.py:578-608; TFP is not installable): scikit-learn's
+    GaussianProcessRegressor with ConstantKernel * Matern(nu=2.01) + WhiteKernel evaluates the same marginal likelihood
+    phi1 R_nu(|s - t| / phi2) + (sigma^2 + jitter) I  with its own Bessel / Cholesky code."""
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import ConstantKernel, Matern, WhiteKernel
+    g = _load(golden_dir, "g3_pipeline.npz")
+    I, X = g["seir3_I"][:61], g["seir3_X_interp"][:61]
+    for d, (p1, p2, s2) in enumerate([(0.02, 0.3, 1e-4), (0.005, 0.8, 4e-4), (0.05, 0.15, 1e-3)]):
+        x, mu = X[:, d], X[:, d].mean()
+        ll, gr = orc.gp_marginal_and_grad(I[:, 0], x, mu, p1, p2, s2, jitter=1e-6)
+        k = ConstantKernel(p1, "fixed") * Matern(length_scale=p2, length_scale_bounds="fixed", nu=2.01) + WhiteKernel(s2 + 1e-6, "fixed")
+        gp = GaussianProcessRegressor(kernel=k, alpha=0.0, optimizer=None).fit(I, x - mu)
+        ref = gp.log_marginal_likelihood_value_
+        assert abs(ll - ref) <= 1e-8 * abs(ref), (d, ll, ref)
+        # gradients: scikit-learn differentiates with respect to log-parameters (and numerically for this nu)
+        k2 = ConstantKernel(p1) * Matern(length_scale=p2, nu=2.01) + WhiteKernel(s2 + 1e-6)
+        gp2 = GaussianProcessRegressor(kernel=k2, alpha=0.0, optimizer=None).fit(I, x - mu)
+        _, gl = gp2.log_marginal_likelihood(gp2.kernel_.theta, eval_gradient=True)          # d/d log(phi1, phi2, noise)
+        mine = np.array([gr[0] * p1, gr[1] * p2, gr[2] * (s2 + 1e-6)])
+        np.testing.assert_allclose(mine[[0, 2]], gl[[0, 2]], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(mine[1], gl[1], rtol=2e-3)        # scikit-learn's length-scale derivative is a finite difference for nu = 2.01
