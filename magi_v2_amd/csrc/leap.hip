@@ -99,7 +99,9 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     double xin[NC][D];
     bool act[NC];
     // (small loads first, the tile stream behind them: their wait then does not cover the row loads)
-    if (wave < NC) {
+    // (blocks of FH multiply xc on both sides: they need no theta and do not wait for it -- their traffic fills the window
+    //  in which the other workgroups derive theta')
+    if (wave < NC && kind != TK_FH) {
         const int c = wave, cc = min(c0 + c, ch.n_chains - 1);
         const LeafPlan* lp = ch.plan + (size_t)(parity ^ 1) * ch.n_chains + cc;
         const bool derive = lp->active && !lp->skip && lp->leaf;
@@ -143,12 +145,19 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) a1[r] = A[(size_t)(8 + r) * (TB / 2)];
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();                 // th_s
     double thv[NC][P];
+    if (kind != TK_FH) {
+        __syncthreads();             // th_s
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int k = 0; k < P; ++k) thv[c][k] = th_s[c][k];
+            for (int k = 0; k < P; ++k) thv[c][k] = th_s[c][k];
+    } else {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int k = 0; k < P; ++k) thv[c][k] = 0.0;
+    }
 
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
