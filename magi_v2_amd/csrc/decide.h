@@ -102,16 +102,27 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
     // and the point phase's partial sums.  These decisions run next to a stream that saturates the memory system, where
     // every dependent round trip costs several microseconds -- their number, not the instruction count, is what matters.
     static_assert(sizeof(ChainCtl) % 4 == 0 && sizeof(ChainCtl) / 4 <= PT_THREADS - 2, "ChainCtl staging");
-    if (tid < (int)(sizeof(ChainCtl) / 4)) reinterpret_cast<int*>(s_ctl)[tid] = reinterpret_cast<const int*>(ch.ctl + chain)[tid];
-    else if (tid == PT_THREADS - 2) s_g[0] = ch.gctl->stop_k;
-    else if (tid == PT_THREADS - 1) s_g[1] = ch.gctl->epoch;
+    // (all loads into registers first, the LDS stores after the last of them: a load followed by its own store is a round trip)
+    int ctl_w = 0;
+    if (tid < (int)(sizeof(ChainCtl) / 4)) ctl_w = reinterpret_cast<const int*>(ch.ctl + chain)[tid];
+    else if (tid == PT_THREADS - 2) ctl_w = ch.gctl->stop_k;
+    else if (tid == PT_THREADS - 1) ctl_w = ch.gctl->epoch;
     LeafPlan* plan_out = ch.plan + (size_t)parity * ch.n_chains + chain;
     const LeafPlan lp = ch.plan[(size_t)(parity ^ 1) * ch.n_chains + chain];     // what the point phase executed last for this chain
-    if (tid >= 64 && tid < 64 + PAR_COUNT) s_par[tid - 64] = ch.par[(size_t)chain * PAR_COUNT + (tid - 64)];
+    const double par_v = (tid >= 64 && tid < 64 + PAR_COUNT) ? ch.par[(size_t)chain * PAR_COUNT + (tid - 64)] : 0.0;
     double pre[RedLayout<DRIFT>::PER_WAVE];
     leap_reduce_issue<DRIFT>(ch, chain, pre);
     static_assert(OPS_W >= MAGI_MAX_D + MAGI_MAX_P, "operand prefetch");
-    reduce_prefetch_ops(pb, ch.vec + vec_off(pb, chain, 0), DriftT<DRIFT>::D + DriftT<DRIFT>::P, s_ops);
+    constexpr int OPS_PER = (OPS_COUNT * OPS_W + PT_THREADS - 1) / PT_THREADS;
+    double ops_v[OPS_PER];
+    reduce_prefetch_ops_load<OPS_PER>(pb, ch.vec + vec_off(pb, chain, 0), DriftT<DRIFT>::D + DriftT<DRIFT>::P, ops_v);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < (int)(sizeof(ChainCtl) / 4)) reinterpret_cast<int*>(s_ctl)[tid] = ctl_w;
+    else if (tid == PT_THREADS - 2) s_g[0] = ctl_w;
+    else if (tid == PT_THREADS - 1) s_g[1] = ctl_w;
+    if (tid >= 64 && tid < 64 + PAR_COUNT) s_par[tid - 64] = par_v;
+    reduce_prefetch_ops_store<OPS_PER>(ops_v, s_ops);
+    MAGI_STAMP(ch.par, 2);
     __syncthreads();
     MAGI_STAMP(ch.par + (size_t)chain * PAR_COUNT, 0);
     ChainCtl c = *s_ctl;

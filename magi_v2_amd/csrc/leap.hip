@@ -109,12 +109,15 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
         if (derive) {
             const double* vb = ch.vec + vec_off(pb, cc, 0);
             const double* part = ch.part + (size_t)cc * PART_K * ch.n_wg;
+            // (every load of the derivation is issued before the first wait)
+            const int e = pb.ND + D + min(lane, P - 1);
+            const double qv = (vb + (size_t)(V_Q + lp->cur) * pb.dimp)[e], pv = (vb + (size_t)(V_P + lp->cur) * pb.dimp)[e];
+            double rows[P];
+            part_rows_sum<P>(part, ch.n_wg, PK_TP, lane, rows);
             double tpp = 0.0;
 #pragma unroll
-            for (int k = 0; k < P; ++k) { const double r = part_row_sum(part, ch.n_wg, PK_TP + k, lane); if (lane == k) tpp = r; }
+            for (int k = 0; k < P; ++k) if (lane == k) tpp = rows[k];
             if (lane < P) {
-                const int e = pb.ND + D + lane;
-                const double qv = (vb + (size_t)(V_Q + lp->cur) * pb.dimp)[e], pv = (vb + (size_t)(V_P + lp->cur) * pb.dimp)[e];
                 const double ex = m_exp(qv);
                 const double sg = ex / (1.0 + ex);                       // == par[PAR_SGT] of that state (compute_par_entry)
                 const double qnx = next_entry_pre(pv, qv, lp->hs, lp->eps, theta_entry_grad(pb.beta_inv, tpp, sg));

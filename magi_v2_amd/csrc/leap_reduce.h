@@ -32,6 +32,19 @@ __device__ __forceinline__ double part_row_sum(const double* part, int nwg, int 
     for (int w = lane; w < nwg; w += 64) v += part[(size_t)row * nwg + w];
     return wave_sum(v);
 }
+// P rows at once, all loads in flight together (the stream's derivation of theta')
+template <int P>
+__device__ __forceinline__ void part_rows_sum(const double* part, int nwg, int row0, int lane, double (&out)[P]) {
+#pragma unroll
+    for (int k = 0; k < P; ++k) out[k] = (lane < nwg) ? part[(size_t)(row0 + k) * nwg + lane] : 0.0;
+    for (int w0 = 64; w0 < nwg; w0 += 64) {
+#pragma unroll
+        for (int k = 0; k < P; ++k) if (w0 + lane < nwg) out[k] += part[(size_t)(row0 + k) * nwg + w0 + lane];
+    }
+#pragma unroll
+    for (int k = 0; k < P; ++k) out[k] = wave_sum(out[k]);
+}
+
 // d L / d theta_pre_p from the global sum tp_p (magi_v2.py:318-323, 335-337 chained through softplus)
 __device__ __forceinline__ double theta_entry_grad(double beta_inv, double tpp, double sg) { return -0.5 * beta_inv * tpp * sg + (1.0 - sg); }
 // position of a parameter entry after completing this leaf's momentum step and taking the next half step
@@ -62,13 +75,19 @@ __device__ __forceinline__ void leap_reduce_issue(const DevChains& ch, int chain
     using RL = RedLayout<DRIFT>;
     const double* part = ch.part + (size_t)chain * PART_K * ch.n_wg;      // [PART_K][n_wg]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwg = ch.n_wg;
+    // every load of the first pass is issued before anything is added: a loop "a += part[...]" per value would make each
+    // value its own round trip (measured: 5 x 1.1 us next to the saturating stream)
 #pragma unroll
     for (int i = 0; i < RL::PER_WAVE; ++i) {
         const int k = wave + RED_WAVES * i;
-        double a = 0.0;
-        if (k < RL::K0 + 8)
-            for (int w = lane; w < nwg; w += 64) a += part[(size_t)RL::row(k) * nwg + w];      // (same order as part_row_sum)
-        v[i] = a;
+        v[i] = (k < RL::K0 + 8 && lane < nwg) ? part[(size_t)RL::row(k) * nwg + lane] : 0.0;
+    }
+    for (int w0 = 64; w0 < nwg; w0 += 64) {                                // (N > 1024; same order of additions as part_row_sum)
+#pragma unroll
+        for (int i = 0; i < RL::PER_WAVE; ++i) {
+            const int k = wave + RED_WAVES * i;
+            if (k < RL::K0 + 8 && w0 + lane < nwg) v[i] += part[(size_t)RL::row(k) * nwg + w0 + lane];
+        }
     }
 }
 
@@ -76,13 +95,26 @@ __device__ __forceinline__ void leap_reduce_issue(const DevChains& ch, int chain
 // position buffers, the subtree momentum sum and all checkpoints -> LDS [OPS_COUNT][OPS_W].
 constexpr int OPS_P = 0, OPS_Q = 2, OPS_RHO = 4, OPS_CKP = 5, OPS_CKR = OPS_CKP + MAGI_MAX_DEPTH, OPS_COUNT = OPS_CKR + MAGI_MAX_DEPTH;
 constexpr int OPS_W = 12;      // >= MAGI_MAX_D + MAGI_MAX_P entries per vector
-__device__ __forceinline__ void reduce_prefetch_ops(const DevProblem& pb, const double* vb, int n_entries, double* ops) {
-    for (int idx = threadIdx.x; idx < OPS_COUNT * OPS_W; idx += blockDim.x) {
+template <int PER>
+__device__ __forceinline__ void reduce_prefetch_ops_load(const DevProblem& pb, const double* vb, int n_entries, double (&tmp)[PER]) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int idx = threadIdx.x + u * MAGI_TAIL_THREADS;
         const int slot = idx / OPS_W, j = idx - slot * OPS_W;
-        if (j >= n_entries) continue;
-        const int vs = slot < OPS_Q ? V_P + slot : slot < OPS_RHO ? V_Q + (slot - OPS_Q) : slot == OPS_RHO ? V_RHOSUB
-                     : slot < OPS_CKR ? V_CKP0 + (slot - OPS_CKP) : V_CKRHO0 + (slot - OPS_CKR);
-        ops[idx] = vb[(size_t)vs * pb.dimp + pb.ND + j];
+        tmp[u] = 0.0;
+        if (idx < OPS_COUNT * OPS_W && j < n_entries) {
+            const int vs = slot < OPS_Q ? V_P + slot : slot < OPS_RHO ? V_Q + (slot - OPS_Q) : slot == OPS_RHO ? V_RHOSUB
+                         : slot < OPS_CKR ? V_CKP0 + (slot - OPS_CKP) : V_CKRHO0 + (slot - OPS_CKR);
+            tmp[u] = vb[(size_t)vs * pb.dimp + pb.ND + j];
+        }
+    }
+}
+template <int PER>
+__device__ __forceinline__ void reduce_prefetch_ops_store(const double (&tmp)[PER], double* ops) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int idx = threadIdx.x + u * MAGI_TAIL_THREADS;
+        if (idx < OPS_COUNT * OPS_W) ops[idx] = tmp[u];
     }
 }
 
@@ -128,10 +160,18 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
         }
     }
 
-    // log(2 pi sigma_d^2) of the evaluated state: a third wave computes it while the partial sums are being added (keeping this
-    // fp64 log out of the chain  exp -> log -> log  that produces the next state's parameters below)
-    if (threadIdx.x >= 128 && threadIdx.x < 128 + D) shs[12 + (threadIdx.x - 128)] = m_log(2.0 * 3.141592653589793 * par_r[PAR_SIG2 + (threadIdx.x - 128)]);
-
+    // t3 = sum_d N_d log(2 pi sigma_d^2) of the evaluated state: a third wave computes it here, under the wait for the first
+    // round of loads (A/B: 0.55 us per slot better than next to wave 1's exp -> log chain below); combined after the barriers
+    if (threadIdx.x >= 128 && threadIdx.x < 192) {
+        const int jd = threadIdx.x - 128;
+        double t3 = 0.0;
+        if (jd < D) {
+            const double nds = (jd == 0) ? pb.N_ds[0] : (jd == 1) ? pb.N_ds[1] : (jd == 2) ? pb.N_ds[2] : pb.N_ds[3];
+            t3 = nds * m_log(2.0 * 3.141592653589793 * par_r[PAR_SIG2 + jd]);
+        }
+        t3 = row16_sum(t3);
+        if (jd == 0) shs[1] = t3;
+    }
     // ---- add the workgroup partials (fixed order: lane = workgroup, butterfly) ------------------------------------------
     constexpr int K0 = 2 + D + P;
     double red[K0 + 8];
@@ -153,12 +193,11 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
 
     // ---- parameter entries: gradient, momentum step, checkpoint, U-turn terms, speculative next state ----
     if (threadIdx.x < 64) {
-        double t3 = 0.0, t4 = 0.0, lj = 0.0, gj = 0.0;
+        double t4 = 0.0, lj = 0.0, gj = 0.0;
         if (j < D) {
             const double sg = par_r[PAR_SGS + j], sj = par_r[PAR_SIG2 + j];
             const double ssd = select_lane<K0 + 8>(red, 1, D, j);
             const double nds = (j == 0) ? pb.N_ds[0] : (j == 1) ? pb.N_ds[1] : (j == 2) ? pb.N_ds[2] : pb.N_ds[3];
-            t3 = nds * shs[12 + j];
             t4 = ssd * (1.0 / sj);
             lj = par_r[PAR_LJS + j];
             gj = -0.5 * (nds / sj - ssd / (sj * sj)) * sg + (1.0 - sg);
@@ -186,14 +225,13 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
                 qn[ND + j] = qj + lp.eps * pnext;
             }
         }
-        t3 = row16_sum(t3); t4 = row16_sum(t4); lj = row16_sum(lj); ppj = row16_sum(ppj);
+        t4 = row16_sum(t4); lj = row16_sum(lj); ppj = row16_sum(ppj);
         if (dots) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { a[k] = row16_sum(a[k]); b[k] = row16_sum(b[k]); }
         }
         if (j == 0) {
-            shs[0] = -0.5 * ((pb.beta_inv * red[0]) + (t3 + t4)) + lj;
-            shs[1] = t3;
+            shs[0] = lj;
             shs[2] = t4;
             shs[3] = red[1 + D + P] + ppj;
 #pragma unroll
@@ -232,7 +270,8 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
         if (used) par[k] = sh[21 * 16 + k];
     }
     ReduceOut o;
-    o.L = shs[0]; o.t12 = red[0]; o.t3 = shs[1]; o.t4 = shs[2]; o.pp = shs[3];
+    o.t12 = red[0]; o.t3 = shs[1]; o.t4 = shs[2]; o.pp = shs[3];
+    o.L = -0.5 * ((pb.beta_inv * red[0]) + (o.t3 + o.t4)) + shs[0];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { o.dA[k] = shs[4 + 2 * k]; o.dB[k] = shs[5 + 2 * k]; }
     __syncthreads();   // shs may be reused by the caller

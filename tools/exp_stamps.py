@@ -25,8 +25,8 @@ u = rows.view(np.uint64)        # the stream's stamps are raw 64-bit counter val
 d = lambda a, b: np.median((rows[:, b] - rows[:, a]) * 10.0)
 # stamps inside the decision workgroup (decide.h): 0 entry (state staged), 1 uniforms issued, 3 partial sums added,
 # 4 reduce done, 5 decision, 6 hot-path end
-print("ns: first round of loads %.0f | ->1 %.0f | add partials %.0f | param entries %.0f | decide %.0f | publish %.0f | total %.0f" %
-      (d(8, 0), d(0, 1), d(1, 3), d(3, 4), d(4, 5), d(5, 6), d(8, 6)))
+print("ns: issue of the first round %.0f | its wait %.0f | ->1 %.0f | add partials %.0f | param entries %.0f | decide %.0f | publish %.0f | total %.0f" %
+      (d(8, 2), d(2, 0), d(0, 1), d(1, 3), d(3, 4), d(4, 5), d(5, 6), d(8, 6)))
 # the slot after the last hot leaf: stream start [12] / latest stream workgroup end [11] (raw counters), decide entry [8] / hot end [6] are of the
 # slot BEFORE; report durations only
 print("stream (first wg start -> last wg end) %.0f ns" % np.median((u[:, 11].astype(np.int64) - u[:, 12].astype(np.int64)) * 10.0))
