@@ -94,7 +94,7 @@ __device__ __forceinline__ LeafPlan make_leaf_plan(const ChainCtl& c, unsigned l
 // All threads of a 256-thread workgroup call it; `parity` = slot whose stream is running next to these decisions
 // (they complete slot parity ^ 1 ... i.e. the slot the point phase executed last, and write plan[parity]).
 template <int DRIFT>
-__device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChains& ch, const SamplerCfgDev& cfg, int chain, int parity,
+__device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChains& ch, const SamplerCfgDev& cfg, int chain, int parity, int all_done,
                                              double* sh /* 25*16 */, double* shs /* 24 */, ChainCtl* s_ctl, int* s_g, double* s_par /* PAR_COUNT */, double* s_ops /* OPS_COUNT * OPS_W */) {
     const int tid = threadIdx.x;
     MAGI_STAMP(ch.par, 8);
@@ -117,6 +117,7 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
     double ops_v[OPS_PER];
     reduce_prefetch_ops_load<OPS_PER>(pb, ch.vec + vec_off(pb, chain, 0), DriftT<DRIFT>::D + DriftT<DRIFT>::P, ops_v);
     __builtin_amdgcn_sched_barrier(0);
+    if (all_done) return;
     if (tid < (int)(sizeof(ChainCtl) / 4)) reinterpret_cast<int*>(s_ctl)[tid] = ctl_w;
     else if (tid == PT_THREADS - 2) s_g[0] = ctl_w;
     else if (tid == PT_THREADS - 1) s_g[1] = ctl_w;

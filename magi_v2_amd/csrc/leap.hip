@@ -66,7 +66,9 @@ __global__ __launch_bounds__(64 * ST_WAVES) __attribute__((amdgpu_waves_per_eu(N
 void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     using DR = DriftT<DRIFT>;
     constexpr int D = DR::D, P = DR::P, TB = MAGI_TB;
-    if (ch.gctl->all_done) return;
+    // (the "all chains idle" flag is fetched here but tested after the other first loads are on the wire: an early return on it
+    //  would put one more dependent round trip in front of every workgroup of every slot)
+    const int all_done = ch.gctl->all_done;
     const int c0 = blockIdx.y * NC;
     __shared__ double vcol[NC][TB], vrow[NC][TB], rowout[NC][TB], colacc[ST_WAVES][NC][TB];
     __shared__ double th_s[NC][MAGI_MAX_P];
@@ -79,7 +81,7 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
         __shared__ double s_par[PAR_COUNT];
         __shared__ double s_ops[OPS_COUNT * OPS_W];
         const int chain = c0 + (int)blockIdx.x;
-        if (chain < ch.n_chains) decide_block<DRIFT>(pb, ch, cfg, chain, parity, dsh, dshs, &s_ctl, s_g, s_par, s_ops);
+        if (chain < ch.n_chains) decide_block<DRIFT>(pb, ch, cfg, chain, parity, all_done, dsh, dshs, &s_ctl, s_g, s_par, s_ops);
         return;
     }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -139,6 +141,14 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
         for (int dd = 0; dd < D; ++dd) xin[c][dd] = q[dd * N + min(gi, N - 1)];
     }
 
+    if (all_done) return;
+#ifdef MAGI_TAIL_STAMPS
+    if (tix == 0 && threadIdx.x == 0) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(ch.par + (size_t)c0 * PAR_COUNT + 40 + 11);
+        st[1] = __builtin_amdgcn_s_memrealtime();      // [12] first stream workgroup's start
+        st[0] = 0ull;                                    // [11] latest stream workgroup end (atomicMax below)
+    }
+#endif
     // the wave's rows in chunks of 8, two chunks in flight (a0 / a1): 16 KB per wave on the wire while one chunk is in the ALUs
     const double2* A = reinterpret_cast<const double2*>(pb.tiles + (size_t)tix * TB * TB + (size_t)(wave * ST_RW) * TB) + lane;
     constexpr int NCK = ST_RW / 8;
@@ -228,16 +238,21 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
             tp[((size_t)(cvec * D + d) * pb.nb + bi) * pb.Np + bj * TB + loc] = sum;
         }
     }
+#ifdef MAGI_TAIL_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned long long*>(ch.par + (size_t)c0 * PAR_COUNT + 40 + 11), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 // ---- point kernel: the elementwise half of slot `parity` (leap_point.h), N / 16 workgroups per chain -------------------------
 template <int DRIFT>
 __global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains ch, int parity) {
-    if (ch.gctl->all_done) return;
     __shared__ double res[PT_POINTS * 4 * 4];
     __shared__ double redk[64 * PART_K];
+    const int all_done = ch.gctl->all_done;                  // (both fetched before either is tested: one round trip, not two)
     const LeafPlan lp = ch.plan[(size_t)parity * ch.n_chains + blockIdx.y];
-    if (!lp.active || lp.skip) return;
+    if (all_done || !lp.active || lp.skip) return;
     point_block<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, res, redk);
 }
 

@@ -17,7 +17,7 @@
 // ends on a slow path still reports the last hot leaf
 static __shared__ double g_stamps[16];
 #define MAGI_STAMP(par, i) do { if (threadIdx.x == 0) g_stamps[(i)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
-#define MAGI_STAMP_FLUSH(par) do { if (threadIdx.x == 0) for (int _i = 0; _i < 16; ++_i) (par)[40 + _i] = g_stamps[_i]; } while (0)
+#define MAGI_STAMP_FLUSH(par) do { if (threadIdx.x == 0) for (int _i = 0; _i < 11; ++_i) (par)[40 + _i] = g_stamps[_i]; } while (0)   /* 11, 12: written by the stream workgroups */
 #else
 #define MAGI_STAMP_FLUSH(par) do { } while (0)
 #define MAGI_STAMP(par, i) do { } while (0)
