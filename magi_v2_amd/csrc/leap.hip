@@ -69,6 +69,7 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     // (the "all chains idle" flag is fetched here but tested after the other first loads are on the wire: an early return on it
     //  would put one more dependent round trip in front of every workgroup of every slot)
     const int all_done = ch.gctl->all_done;
+    kernarg_prefetch<sizeof(DevProblem) + sizeof(DevChains) + sizeof(SamplerCfgDev) + sizeof(int)>();
     const int c0 = blockIdx.y * NC;
     __shared__ double vcol[NC][TB], vrow[NC][TB], rowout[NC][TB], colacc[ST_WAVES][NC][TB];
     __shared__ double th_s[NC][MAGI_MAX_P];
@@ -250,9 +251,13 @@ template <int DRIFT>
 __global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains ch, int parity) {
     __shared__ double res[PT_POINTS * 4 * 4];
     __shared__ double redk[64 * PART_K];
-    const int all_done = ch.gctl->all_done;                  // (both fetched before either is tested: one round trip, not two)
+    // (flag and plan are fetched together and combined arithmetically: `a || b` would fetch b only after a has arrived --
+    //  one more dependent round trip at the head of a 5 us kernel)
+    const int all_done = ch.gctl->all_done;
     const LeafPlan lp = ch.plan[(size_t)parity * ch.n_chains + blockIdx.y];
-    if (all_done || !lp.active || lp.skip) return;
+    kernarg_prefetch<sizeof(DevProblem) + sizeof(DevChains) + sizeof(int)>();
+    const int gate = all_done | (lp.active ^ 1) | lp.skip;
+    if (gate != 0) return;
     point_block<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, res, redk);
 }
 

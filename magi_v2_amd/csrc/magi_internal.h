@@ -178,6 +178,23 @@ __host__ __device__ inline size_t vec_off(const DevProblem& pb, int chain, int s
 }
 
 // ------------------------------------------------------------------------------------------
+// Kernel arguments are ~0.5 KB of structs passed by value; the compiler fetches their cache lines lazily, next to the
+// first use, and every first touch of a line is a scalar-cache miss on the critical path of a 5 us kernel (k_point had
+// four such waits in a row before its first vector load).  Touching every line up front turns them into one.
+// ------------------------------------------------------------------------------------------
+template <int BYTES>
+__device__ __forceinline__ void kernarg_prefetch() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const unsigned __attribute__((address_space(4))) * ka_ptr;
+    ka_ptr ka = (ka_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned t = 0;
+#pragma unroll
+    for (int o = 0; o < BYTES; o += 64) t |= ka[o / 4];
+    asm volatile("" ::"s"(t));
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011), identical to oracle/magi_oracle.py::philox4x32
 // ------------------------------------------------------------------------------------------
 struct Philox4 { unsigned int x, y, z, w; };
