@@ -88,6 +88,18 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int tix = (int)blockIdx.x - n_dec;
     const int4 task = reinterpret_cast<const int4*>(pb.tasks)[tix];
+    // the wave's rows in chunks of 8, two chunks in flight (a0 / a1): 16 KB per wave on the wire while one chunk is in the ALUs.
+    // tile loads need nothing but the block index: on the wire before the plan-dependent loads (except in the waves that derive theta')
+    const double2* A = reinterpret_cast<const double2*>(pb.tiles + (size_t)tix * TB * TB + (size_t)((threadIdx.x >> 6) * ST_RW) * TB) + (threadIdx.x & 63);
+    constexpr int NCK = ST_RW / 8;
+    double2 a0[8], a1[8];
+    if ((threadIdx.x >> 6) >= NC) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a0[r] = A[(size_t)r * (TB / 2)];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a1[r] = A[(size_t)(8 + r) * (TB / 2)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     const int d = task.x, kind = task.y, bi = task.z, bj = task.w;
     const int N = pb.N;
 
@@ -150,14 +162,12 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
         st[0] = 0ull;                                    // [11] latest stream workgroup end (atomicMax below)
     }
 #endif
-    // the wave's rows in chunks of 8, two chunks in flight (a0 / a1): 16 KB per wave on the wire while one chunk is in the ALUs
-    const double2* A = reinterpret_cast<const double2*>(pb.tiles + (size_t)tix * TB * TB + (size_t)(wave * ST_RW) * TB) + lane;
-    constexpr int NCK = ST_RW / 8;
-    double2 a0[8], a1[8];
+    if (wave < NC) {                 // (the waves that derived theta' issue their first chunks now)
 #pragma unroll
-    for (int r = 0; r < 8; ++r) a0[r] = A[(size_t)r * (TB / 2)];
+        for (int r = 0; r < 8; ++r) a0[r] = A[(size_t)r * (TB / 2)];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) a1[r] = A[(size_t)(8 + r) * (TB / 2)];
+        for (int r = 0; r < 8; ++r) a1[r] = A[(size_t)(8 + r) * (TB / 2)];
+    }
     __builtin_amdgcn_sched_barrier(0);
     double thv[NC][P];
     if (kind != TK_FH) {
