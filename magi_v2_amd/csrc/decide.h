@@ -41,6 +41,25 @@ __device__ __forceinline__ TailVecs tail_vecs(const DevProblem& pb, double* vb) 
     return v;
 }
 
+// State-sized loops of the rare paths (subtree ends, transition ends), one workgroup over `dim` entries: written element by
+// element (`dst[e] = src[e]`) every iteration is its own memory round trip -- DB elements' loads are issued together instead.
+constexpr int DB = 4;
+__device__ __forceinline__ void copy2_batched(double* d0, const double* s0, double* d1, const double* s1, int dim) {
+    for (int e0 = threadIdx.x; e0 < dim; e0 += DB * (int)blockDim.x) {
+        double a[DB], b[DB];
+#pragma unroll
+        for (int u = 0; u < DB; ++u) {
+            const int e = e0 + u * (int)blockDim.x;
+            if (e < dim) { a[u] = s0[e]; if (s1) b[u] = s1[e]; }
+        }
+#pragma unroll
+        for (int u = 0; u < DB; ++u) {
+            const int e = e0 + u * (int)blockDim.x;
+            if (e < dim) { d0[e] = a[u]; if (d1) d1[e] = b[u]; }
+        }
+    }
+}
+
 // DualAveragingStepSizeAdaptation.one_step after the inner NUTS step (oracle: dual_averaging_update).
 // Evaluated by one thread; results returned through out[0..3].
 __device__ __noinline__ void dual_averaging_eval(double target_accept, int n_adapt, int prev, double da_step_size, double da_error_sum,
@@ -181,7 +200,7 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
 
         if (!leaf) {
             // bootstrap_results: target / gradient at the initial state, cached at beta_temp(0)
-            for (int e = tid; e < dim; e += blockDim.x) { v.candq[e] = qcur[e]; v.candg[e] = v.g[e]; }
+            copy2_batched(v.candq, qcur, v.candg, v.g, dim);
             c.cand_L = L;
             c.beta_cache = shs[16];
             if (c.k < stop_k) do_sample = true;
@@ -202,7 +221,8 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
                 const double* cp = v.ckp + (size_t)__popc((unsigned)left) * sv;
                 const double* cr = v.ckrho + (size_t)__popc((unsigned)left) * sv;
                 double dots[2] = {0.0, 0.0};
-                for (int e = tid; e < dim; e += blockDim.x) {
+#pragma unroll 4
+                for (int e = tid; e < dim; e += blockDim.x) {     // (no stores: unrolling puts four elements' loads in flight together)
                     const double df = v.rhosub[e] - cr[e];
                     dots[0] = fma(df, cp[e], dots[0]);
                     dots[1] = fma(df, pleaf[e], dots[1]);
@@ -235,7 +255,7 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
             if (c.it < c.nsteps && c.cont) {
                 // ---- the speculative next leaf stands: flip buffers, publish its plan -------------------------
                 if (accept_leaf) {                   // proposal copy (expected O(log n) times per subtree)
-                    for (int e = tid; e < dim; e += blockDim.x) { v.subq[e] = qcur[e]; v.subg[e] = v.g[e]; }
+                    copy2_batched(v.subq, qcur, v.subg, v.g, dim);
                 }
                 c.cur = lp.cur ^ 1;
                 if (tid == 0) {
@@ -258,17 +278,32 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
             double* ge = (c.dir > 0) ? v.gR : v.gL;
             const double* po_ = (c.dir > 0) ? v.pL : v.pR;    // the other end
             double dots[2] = {0.0, 0.0};
-            for (int e = tid; e < dim; e += blockDim.x) {
-                const double qv = qcur[e], gv = v.g[e];
-                // the subtree proposal is this leaf if it was just accepted, else what V_SUB holds
-                const double sq = (accept_leaf || hmc) ? qv : v.subq[e], sg = (accept_leaf || hmc) ? gv : v.subg[e];
-                if (choose) { v.candq[e] = sq; v.candg[e] = sg; }
-                const double pn = pleaf[e];
-                pe[e] = pn; qe[e] = qv; ge[e] = gv;
-                const double rr = v.rho[e] + v.rhosub[e];
-                v.rho[e] = rr;
-                dots[0] = fma(rr, po_[e], dots[0]);
-                dots[1] = fma(rr, pn, dots[1]);
+            const bool take_leaf = accept_leaf || hmc;
+            for (int e0 = tid; e0 < dim; e0 += DB * (int)blockDim.x) {       // DB elements' loads in flight, then their stores
+                double qv[DB], gv[DB], sq[DB], sg[DB], pn[DB], rr[DB], po[DB];
+#pragma unroll
+                for (int u = 0; u < DB; ++u) {
+                    const int e = e0 + u * (int)blockDim.x;
+                    if (e < dim) {
+                        qv[u] = qcur[e]; gv[u] = v.g[e];
+                        // the subtree proposal is this leaf if it was just accepted, else what V_SUB holds
+                        sq[u] = take_leaf ? qv[u] : v.subq[e]; sg[u] = take_leaf ? gv[u] : v.subg[e];
+                        pn[u] = pleaf[e];
+                        rr[u] = v.rho[e] + v.rhosub[e];
+                        po[u] = po_[e];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < DB; ++u) {
+                    const int e = e0 + u * (int)blockDim.x;
+                    if (e < dim) {
+                        if (choose) { v.candq[e] = sq[u]; v.candg[e] = sg[u]; }
+                        pe[e] = pn[u]; qe[e] = qv[u]; ge[e] = gv[u];
+                        v.rho[e] = rr[u];
+                        dots[0] = fma(rr[u], po[u], dots[0]);
+                        dots[1] = fma(rr[u], pn[u], dots[1]);
+                    }
+                }
             }
             block_sum<2>(dots, sh);        // (its barriers publish shs[20])
             if (hmc) { c.sub_L = L; c.sub_energy = energy; }
@@ -304,7 +339,7 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
                 }
                 if (k >= cfg.burnin) {
                     double* out = ch.samples + ((size_t)chain * (cfg.total - cfg.burnin) + (k - cfg.burnin)) * pb.dimp;
-                    for (int e = tid; e < dim; e += blockDim.x) out[e] = v.candq[e];
+                    copy2_batched(out, v.candq, nullptr, nullptr, dim);
                 }
                 if (c.is_accepted) c.beta_cache = c.beta_k;
                 c.da_step_size = shs[1];
@@ -334,13 +369,24 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
         __syncthreads();
         if (tid == 0) shs[4] = cfg.anneal ? temperature(c.k, cfg.min_temp) : 1.0;
         double pp0[1] = {0.0};
-        for (int e = tid; e < dim; e += blockDim.x) {
-            const double z = rng_normal_elem((unsigned)e, (unsigned)c.k, (unsigned)c.chain_id, cfg.seed);
-            pp0[0] = fma(z, z, pp0[0]);
-            v.pL[e] = z; v.pR[e] = z; v.rho[e] = z;
-            const double qq = v.candq[e], gg = v.candg[e];
-            v.qL[e] = qq; v.qR[e] = qq;
-            v.gL[e] = gg; v.gR[e] = gg;
+        for (int e0 = tid; e0 < dim; e0 += DB * (int)blockDim.x) {
+            double qq[DB], gg[DB];
+#pragma unroll
+            for (int u = 0; u < DB; ++u) {
+                const int e = e0 + u * (int)blockDim.x;
+                if (e < dim) { qq[u] = v.candq[e]; gg[u] = v.candg[e]; }
+            }
+#pragma unroll
+            for (int u = 0; u < DB; ++u) {
+                const int e = e0 + u * (int)blockDim.x;
+                if (e < dim) {
+                    const double z = rng_normal_elem((unsigned)e, (unsigned)c.k, (unsigned)c.chain_id, cfg.seed);
+                    pp0[0] = fma(z, z, pp0[0]);
+                    v.pL[e] = z; v.pR[e] = z; v.rho[e] = z;
+                    v.qL[e] = qq[u]; v.qR[e] = qq[u];
+                    v.gL[e] = gg[u]; v.gR[e] = gg[u];
+                }
+            }
         }
         block_sum<1>(pp0, sh);              // (its barriers also publish shs[4])
         c.beta_k = shs[4];
@@ -376,13 +422,25 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
         c.cur ^= 1;
         double* qw = vb + (size_t)(V_Q + c.cur) * sv;
         double* pw = vb + (size_t)(V_P + c.cur) * sv;
-        for (int e = tid; e < dim; e += blockDim.x) {
-            const double ph = pe[e] + hs * ge[e];
-            pw[e] = ph;
-            const double qn = qe[e] + eps * ph;
-            qw[e] = qn;
-            v.rhosub[e] = 0.0;
-            if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par);
+        for (int e0 = tid; e0 < dim; e0 += DB * (int)blockDim.x) {
+            double p0[DB], g0[DB], q0[DB];
+#pragma unroll
+            for (int u = 0; u < DB; ++u) {
+                const int e = e0 + u * (int)blockDim.x;
+                if (e < dim) { p0[u] = pe[e]; g0[u] = ge[e]; q0[u] = qe[e]; }
+            }
+#pragma unroll
+            for (int u = 0; u < DB; ++u) {
+                const int e = e0 + u * (int)blockDim.x;
+                if (e < dim) {
+                    const double ph = p0[u] + hs * g0[u];
+                    pw[e] = ph;
+                    const double qn = q0[u] + eps * ph;
+                    qw[e] = qn;
+                    v.rhosub[e] = 0.0;
+                    if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par);
+                }
+            }
         }
         c.nsteps = hmc ? cfg.hmc_L : (1 << c.depth);
         c.it = 0;
