@@ -3,8 +3,8 @@ into what the engine needs.
 
 The reference traces an arbitrary Python callable ``f_vec(t[N,1], X[N,D], theta[P]) -> [N,D]`` into XLA and
 lets autodiff produce the Jacobians.  Here the callable is traced once with sympy symbols in numpy object
-arrays (slicing, arithmetic, ``np.sum / np.concatenate / np.reshape / np.stack`` and sympy functions all work
-on those), differentiated symbolically, and emitted twice:
+arrays (slicing, arithmetic, ``np.sum / np.concatenate / np.reshape / np.stack`` and the unary ufuncs
+``np.exp / log / sqrt / sin / cos / tanh`` all work on those), differentiated symbolically, and emitted twice:
 
 * vectorised numpy evaluators of f, df/dx and df/dtheta (host-side initialisation: theta / unobserved-component
   fits, magi_v2.py:133-268), and
@@ -53,24 +53,68 @@ class Drift:
         return self.device_id != USER_ID
 
 
+class _Tr:
+    """Tracing scalar: a sympy expression that also answers the method calls numpy's unary ufuncs make on object arrays
+    (``np.exp(X)`` calls ``x.exp()`` on every entry), so drifts with exp / log / sqrt / sin / cos / tanh trace like polynomial ones."""
+    __slots__ = ("e",)
+
+    def __init__(self, e):
+        self.e = e
+
+    @staticmethod
+    def _u(o):
+        return o.e if isinstance(o, _Tr) else o
+
+    # (an ndarray operand is left to numpy, which then applies the operation entry by entry)
+    def _bin(self, o, f):
+        return NotImplemented if isinstance(o, np.ndarray) else _Tr(f(self.e, _Tr._u(o)))
+
+    def __add__(self, o): return self._bin(o, lambda a, b: a + b)
+    def __radd__(self, o): return self._bin(o, lambda a, b: b + a)
+    def __sub__(self, o): return self._bin(o, lambda a, b: a - b)
+    def __rsub__(self, o): return self._bin(o, lambda a, b: b - a)
+    def __mul__(self, o): return self._bin(o, lambda a, b: a * b)
+    def __rmul__(self, o): return self._bin(o, lambda a, b: b * a)
+    def __truediv__(self, o): return self._bin(o, lambda a, b: a / b)
+    def __rtruediv__(self, o): return self._bin(o, lambda a, b: b / a)
+    def __pow__(self, o): return self._bin(o, lambda a, b: a ** b)
+    def __rpow__(self, o): return self._bin(o, lambda a, b: b ** a)
+    def __neg__(self): return _Tr(-self.e)
+    def __pos__(self): return self
+
+    def exp(self): return _Tr(_sympy().exp(self.e))
+    def log(self): return _Tr(_sympy().log(self.e))
+    def sqrt(self): return _Tr(_sympy().sqrt(self.e))
+    def sin(self): return _Tr(_sympy().sin(self.e))
+    def cos(self): return _Tr(_sympy().cos(self.e))
+    def tanh(self): return _Tr(_sympy().tanh(self.e))
+    def square(self): return _Tr(self.e ** 2)
+    def reciprocal(self): return _Tr(1 / self.e)
+
+
 def _trace(f_vec: Callable, D: int, P: int):
     sp = _sympy()
     xs = sp.symbols(f"x0:{D}", real=True)
     ths = sp.symbols(f"th0:{P}", real=True)
     tsym = sp.Symbol("t_magi", real=True)
-    X = np.array([list(xs)], dtype=object)
-    th = np.array(list(ths), dtype=object)
-    t = np.array([[tsym]], dtype=object)
+    X = np.empty((1, D), dtype=object)
+    for k in range(D):
+        X[0, k] = _Tr(xs[k])
+    th = np.empty((P,), dtype=object)
+    for k in range(P):
+        th[k] = _Tr(ths[k])
+    t = np.empty((1, 1), dtype=object)
+    t[0, 0] = _Tr(tsym)
     try:
         out = f_vec(t, X, th)
     except Exception as exc:
         raise NotImplementedError(
-            "f_vec could not be traced: write it with numpy-compatible operations (slicing, + - * /, np.sum, "
-            "np.concatenate, np.reshape, np.stack, sympy functions) -- " + repr(exc)) from exc
+            "f_vec could not be traced: write it with numpy-compatible operations (slicing, + - * / **, np.sum, "
+            "np.concatenate, np.reshape, np.stack, np.exp / log / sqrt / sin / cos / tanh) -- " + repr(exc)) from exc
     out = np.asarray(out, dtype=object)
     if out.shape != (1, D):
         raise ValueError(f"f_vec must return an array of shape [N, D]; traced shape {out.shape} for D = {D}")
-    exprs = [sp.sympify(out[0, d]) for d in range(D)]
+    exprs = [sp.sympify(_Tr._u(out[0, d])) for d in range(D)]
     for e in exprs:
         if e.has(tsym):
             raise NotImplementedError("non-autonomous drifts (explicit use of t) are not supported")

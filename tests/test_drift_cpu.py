@@ -98,3 +98,21 @@ def test_gradient_matching_objective_matches_oracle_and_finite_differences(golde
     for i in (0, 1, 40, m.mag_I - 2, m.mag_I - 1):
         E = np.zeros_like(Xu); E[i, 0] = 1e-6
         assert abs((ref(Xu + E, th) - ref(Xu - E, th)) / 2e-6 - gX[i, 0]) <= 1e-5 * max(1.0, abs(gX[i, 0]))
+
+
+def test_transcendental_drifts_trace_through_numpy_ufuncs():
+    """np.exp / np.sqrt / np.tanh on the tracing arrays (numpy calls x.exp() on object entries): a saturating-growth drift."""
+    def f_vec(t, X, th):
+        x, y = X[:, 0:1], X[:, 1:2]
+        return np.concatenate([th[0] * x * np.exp(-th[1] * y) - np.sqrt(1.0 + x ** 2), np.tanh(th[2] * x) - y / (1.0 + y ** 2)], axis=1)
+    d = drift.trace_drift(f_vec, 2, 3)
+    rng = np.random.default_rng(4)
+    X, th = rng.uniform(0.1, 1.5, (9, 2)), rng.uniform(0.3, 2.0, 3)
+    np.testing.assert_allclose(d.f_np(None, X, th), f_vec(None, X, th), rtol=1e-14, atol=1e-15)
+    J, T = d.jac_np(X, th)
+    Jc, Tc = complex_step_jacobians(f_vec, X, th)
+    np.testing.assert_allclose(J, Jc, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(T, Tc, rtol=1e-12, atol=1e-14)
+    for tok in ("exp(", "sqrt(", "tanh("):
+        assert tok in d.header
+    assert os.path.exists(jit.library_for(d))              # the emitted header compiles for gfx950
