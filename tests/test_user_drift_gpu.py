@@ -98,3 +98,26 @@ def test_user_drift_through_the_api_and_posterior_is_centred_on_the_truth():
     assert res["X_samps"].shape == (2, 200, 161, 2) and np.isfinite(res["X_samps"]).all()
     th = res["thetas_samps"].reshape(-1, 3).mean(axis=0)
     assert np.all(np.abs(th - truth) < np.array([0.1, 0.25, 0.4])), th
+
+
+def test_tiny_grid_runs_and_matches_oracle():
+    """Smallest sensible problem (N = 11 grid points, one operator block, one point workgroup): gradient and a short chain."""
+    eng, pr, Xhat, hp, truth = make_problem("lotka_volterra", N=11)
+    rng = np.random.default_rng(6)
+    X = Xhat + rng.normal(0, 0.02, Xhat.shape)
+    sp, tp = rng.normal(-3, 0.3, 2), rng.normal(0.3, 0.3, 4)
+    L, gX, gs, gt = orc.logpost_grad(X, sp, tp, 1.0, pr)
+    for fused in (False, True):
+        out = eng.logpost_grad(X, sp, tp, 1.0, fused=fused)
+        assert abs(out[0] - L) <= 1e-9 * abs(L)
+        np.testing.assert_allclose(out[1], gX, rtol=0, atol=1e-9 * np.abs(gX).max())
+    sp0, tp0 = host.softplus_inverse_inits(hp["sigma_sqs"], np.ones(4), pr.LB)
+    cfg = eng.default_cfg(num_results=3, num_burnin_steps=5, stale_cache=0)
+    eng.sampler_init(cfg, Xhat, sp0, tp0, seed=5)
+    eng.sampler_run(8)
+    _, _, tp_s = eng.sampler_samples()
+    trace = []
+    _, _, otp, _, _ = orc.sample_chain(pr, Xhat, hp["sigma_sqs"], np.ones(4), 3, 5, seed=5, stale_cache=False, trace=trace)
+    np.testing.assert_array_equal(eng.sampler_diag().leapfrogs_taken[0], [r.leapfrogs for _, r, _ in trace])
+    np.testing.assert_allclose(tp_s[0], otp, rtol=1e-7, atol=1e-9)
+    eng.close()
