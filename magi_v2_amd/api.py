@@ -134,8 +134,10 @@ class MAGI_v2:
         values.  ``hparam_fit_on="observed"`` is a documented deviation: it fits on the observation times only.
         The inserted grid points are exact linear interpolants, which a GP marginal likelihood can only explain
         with a short length scale and near-zero noise; on the vignette data that optimum (phi2 ~ 0.1,
-        sigma ~ 0.002) ruins the parameter recovery (theta ~ 1.5 instead of 6), while the fit on the observed
-        rows lands at the true noise level and recovers theta = (5.9, 0.56, 1.75) -- see DESIGN.md section 8."""
+        sigma ~ 0.002) ruins the parameter recovery, while the fit on the observed rows lands at the true noise level
+        (theta ~ (3.9, 0.47, 1.66) against the truth (6, 0.6, 1.8); with phi2 = 0.5 and that noise level
+        (5.9, 0.56, 1.76)) -- see DESIGN.md section 8 and examples/vignette_seir.py.  Components that are never
+        observed are initialised as in magi_v2.py:182-268; ``init_seed`` seeds the reference's unseeded start."""
         self.I, self.X_obs_discret = host.discretize(self.ts_obs, self.X_obs, discretization)
         self.mag_I = self.I.shape[0]
         N_ds, self.beta, idx, y = host.observation_bookkeeping(self.X_obs, self.X_obs_discret)
