@@ -202,7 +202,7 @@ int magi_set_matrices(magi_handle* h, int N, int D, int bandsize, const double* 
                       const double* K_inv) {
     if (!h) return MAGI_E_BADARG;
     if (!C_inv || !m || !K_inv) return magi_fail(h, MAGI_E_BADARG, "null matrix pointer");
-    if (N < 2 || D < 1 || D > MAGI_MAX_D) return magi_fail(h, MAGI_E_BADARG, "need N >= 2 and 1 <= D <= 4");
+    if (N < 2 || D < 1 || D > MAGI_MAX_D) return magi_fail(h, MAGI_E_BADARG, "need N >= 2 and 1 <= D <= " + std::to_string(MAGI_MAX_D));
     (void)hipSetDevice(h->device);
     const size_t bytes = (size_t)D * N * N * sizeof(double);
     double *dC = nullptr, *dm = nullptr, *dK = nullptr;
@@ -222,7 +222,7 @@ int magi_build_matrices(magi_handle* h, const double* I, int N, int D, const dou
                         double nu, int bandsize, double* C_inv, double* m, double* K_inv) {
     if (!h) return MAGI_E_BADARG;
     if (!I || !phi1 || !phi2) return magi_fail(h, MAGI_E_BADARG, "null pointer");
-    if (N < 2 || D < 1 || D > MAGI_MAX_D) return magi_fail(h, MAGI_E_BADARG, "need N >= 2 and 1 <= D <= 4");
+    if (N < 2 || D < 1 || D > MAGI_MAX_D) return magi_fail(h, MAGI_E_BADARG, "need N >= 2 and 1 <= D <= " + std::to_string(MAGI_MAX_D));
     if (!(nu > 1.0)) return magi_fail(h, MAGI_E_BADARG, "nu must exceed 1 (once-differentiable Matern)");
     (void)hipSetDevice(h->device);
     return magi_build_matrices_device(h, I, N, D, phi1, phi2, nu, bandsize, C_inv, m, K_inv);

@@ -12,9 +12,6 @@
 
 namespace {
 
-__device__ __forceinline__ double sel4(const double (&a)[MAGI_MAX_D], int d) {
-    return d == 0 ? a[0] : d == 1 ? a[1] : d == 2 ? a[2] : a[3];
-}
 
 // Transposed butterfly: v[0..8) per lane -> every lane returns the 64-lane sum of v[lane >> 3].
 // Halving steps hand half of the values to the partner (v_permlane32/16_swap move both halves in one
@@ -110,7 +107,7 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     const int loc = (isrow ? t - TB : t) & (TB - 1);
     const int gi = (isrow ? bi : bj) * TB + loc;
     const bool wantf = isrow ? (kind != TK_FH) : (kind == TK_FK);
-    const double mud = sel4(pb.mu, d);
+    const double mud = MAGI_SEL_D(pb.mu, d);
     double xin[NC][D];
     bool act[NC];
     // (small loads first, the tile stream behind them: their wait then does not cover the row loads)
@@ -259,7 +256,7 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
 // ---- point kernel: the elementwise half of slot `parity` (leap_point.h), N / 16 workgroups per chain -------------------------
 template <int DRIFT>
 __global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains ch, int parity) {
-    __shared__ double res[PT_POINTS * 4 * 4];
+    __shared__ double res[PT_POINTS * PT_DSLOT * 4];
     __shared__ double redk[64 * PART_K];
     // (flag and plan are fetched together and combined arithmetically: `a || b` would fetch b only after a has arrived --
     //  one more dependent round trip at the head of a 5 us kernel)

@@ -12,8 +12,9 @@
 #include "magi_internal.h"
 #include "leap_reduce.h"
 
-constexpr int PT_POINTS = 16;                  // grid points per workgroup
-constexpr int PT_THREADS = 256;                // = PT_POINTS x 4 components x 4 products
+constexpr int PT_DSLOT = MAGI_MAX_D;            // component lanes per grid point (4, or 8 in a library built for 5..8 components)
+constexpr int PT_POINTS = 64 / PT_DSLOT;       // grid points per workgroup
+constexpr int PT_THREADS = 256;                // = PT_POINTS x PT_DSLOT components x 4 products
 
 template <int DRIFT>
 struct GridPoint {     // component d of grid index i of one chain (one lane)
@@ -102,22 +103,22 @@ struct GridPoint {     // component d of grid index i of one chain (one lane)
     }
 };
 
-// All PT_THREADS threads of the block must call it.  res: PT_POINTS*4*4 doubles, redk: 64*PART_K doubles of LDS.
+// All PT_THREADS threads of the block must call it.  res: PT_POINTS*PT_DSLOT*4 doubles, redk: 64*PART_K doubles of LDS.
 // Writes part[cc][k][blk].  `lp`: the chain's plan for this slot (active, not skip).
 template <int DRIFT>
 __device__ __forceinline__ void point_block(const DevProblem& pb, const DevChains& ch, const LeafPlan& lp, int cc, int blk, double* res, double* redk) {
     using GP = GridPoint<DRIFT>;
     constexpr int D = GP::D, TB = MAGI_TB;
-    const int t = threadIdx.x;
+    const unsigned t = threadIdx.x;
     // finishing lanes: t < 64 = (component, point)
-    const int fpt = t & (PT_POINTS - 1), fd = (t >> 4) & 3;
+    const int fpt = t & (PT_POINTS - 1), fd = (t / PT_POINTS) & (PT_DSLOT - 1);
     const int fi = blk * PT_POINTS + fpt;
     const bool fvalid = (t < 64) && (fd < D) && (fi < pb.N);
     typename GP::Ops ops;
     if (fvalid) ops = GP::load(pb, ch, lp, cc, fi, fd);
     // product lanes: t = (component, product, point)
     {
-        const int pt = t & (PT_POINTS - 1), v = (t >> 4) & 3, d = t >> 6;
+        const int pt = t & (PT_POINTS - 1), v = (t / PT_POINTS) & 3, d = t / (PT_POINTS * 4);
         const int i = blk * PT_POINTS + pt;
         double sum = 0.0;
         if (d < D && i < pb.N) {
@@ -133,13 +134,13 @@ __device__ __forceinline__ void point_block(const DevProblem& pb, const DevChain
             }
             for (; sl <= s1; ++sl) sum += src[(size_t)sl * pb.Np];
         }
-        res[(pt * 4 + d) * 4 + v] = sum;
+        res[(pt * PT_DSLOT + d) * 4 + v] = sum;
     }
     __syncthreads();
     if (t < 64) {
         double* pk = redk + (size_t)t * PART_K;
         if (fvalid) {
-            GP::finish(pb, ch, lp, cc, fi, fd, ops, res + fpt * 16, pk);
+            GP::finish(pb, ch, lp, cc, fi, fd, ops, res + fpt * PT_DSLOT * 4, pk);
         } else {
 #pragma unroll
             for (int k = 0; k < PART_K; ++k) pk[k] = 0.0;

@@ -8,7 +8,7 @@
 // finish the D + P parameter entries (whose gradients are global sums), and hand the totals to the caller's
 // decision logic.
 //
-// PART layout: [0] t12  [1..4] ss_d  [5..10] tp_p  [11] p.p  [12+2k, 13+2k] U-turn dots of check k
+// PART layout: [0] t12  [1 .. MAX_D] ss_d  [PK_TP ..] tp_p  [PK_PP] p.p  [PK_DOT + 2k, + 2k + 1] U-turn dots of check k
 #pragma once
 #include "magi_internal.h"
 
@@ -23,7 +23,8 @@ static __shared__ double g_stamps[16];
 #define MAGI_STAMP(par, i) do { } while (0)
 #endif
 
-constexpr int PK_T12 = 0, PK_SS = 1, PK_TP = 5, PK_PP = 11, PK_DOT = 12;
+constexpr int PK_T12 = 0, PK_SS = 1, PK_TP = 1 + MAGI_MAX_D, PK_PP = PK_TP + MAGI_MAX_P, PK_DOT = PK_PP + 1;
+static_assert(PK_DOT + 8 <= PART_K, "PART layout");
 
 // ---- pieces shared bit for bit by the decisions (below) and by k_stream, which derives the next theta itself ----
 // sum of one PART row over the point workgroups: whole wave, lane = workgroup, fixed order
@@ -94,7 +95,7 @@ __device__ __forceinline__ void leap_reduce_issue(const DevChains& ch, int chain
 // The parameter entries (index >= N D) of every vector the reduce may need, whatever the plan says: both momentum /
 // position buffers, the subtree momentum sum and all checkpoints -> LDS [OPS_COUNT][OPS_W].
 constexpr int OPS_P = 0, OPS_Q = 2, OPS_RHO = 4, OPS_CKP = 5, OPS_CKR = OPS_CKP + MAGI_MAX_DEPTH, OPS_COUNT = OPS_CKR + MAGI_MAX_DEPTH;
-constexpr int OPS_W = 12;      // >= MAGI_MAX_D + MAGI_MAX_P entries per vector
+constexpr int OPS_W = MAGI_MAX_D + MAGI_MAX_P + 2;      // entries per vector
 template <int PER>
 __device__ __forceinline__ void reduce_prefetch_ops_load(const DevProblem& pb, const double* vb, int n_entries, double (&tmp)[PER]) {
 #pragma unroll
@@ -166,7 +167,7 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
         const int jd = threadIdx.x - 128;
         double t3 = 0.0;
         if (jd < D) {
-            const double nds = (jd == 0) ? pb.N_ds[0] : (jd == 1) ? pb.N_ds[1] : (jd == 2) ? pb.N_ds[2] : pb.N_ds[3];
+            const double nds = MAGI_SEL_D(pb.N_ds, jd);
             t3 = nds * m_log(2.0 * 3.141592653589793 * par_r[PAR_SIG2 + jd]);
         }
         t3 = row16_sum(t3);
@@ -197,7 +198,7 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
         if (j < D) {
             const double sg = par_r[PAR_SGS + j], sj = par_r[PAR_SIG2 + j];
             const double ssd = select_lane<K0 + 8>(red, 1, D, j);
-            const double nds = (j == 0) ? pb.N_ds[0] : (j == 1) ? pb.N_ds[1] : (j == 2) ? pb.N_ds[2] : pb.N_ds[3];
+            const double nds = MAGI_SEL_D(pb.N_ds, j);
             t4 = ssd * (1.0 / sj);
             lj = par_r[PAR_LJS + j];
             gj = -0.5 * (nds / sj - ssd / (sj * sj)) * sg + (1.0 - sg);
@@ -247,7 +248,7 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
             if (jj < D) {
                 const double sg = par_r[PAR_SGS + jj], sj = par_r[PAR_SIG2 + jj];
                 const double ssd = select_lane<K0 + 8>(red, 1, D, jj);
-                const double nds = (jj == 0) ? pb.N_ds[0] : (jj == 1) ? pb.N_ds[1] : (jj == 2) ? pb.N_ds[2] : pb.N_ds[3];
+                const double nds = MAGI_SEL_D(pb.N_ds, jj);
                 gj = -0.5 * (nds / sj - ssd / (sj * sj)) * sg + (1.0 - sg);
             } else {
                 const double sg = par_r[PAR_SGT + (jj - D)];

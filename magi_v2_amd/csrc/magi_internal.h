@@ -11,11 +11,27 @@
 
 #include "../../include/magi_hip.h"
 
-#define MAGI_MAX_D 4        // compiled-in drifts have D <= 4, P <= 5
+#ifndef MAGI_MAX_D
+#define MAGI_MAX_D 4        // compiled-in drifts have D <= 4, P <= 5; a library built for a traced drift with 5..8 components sets 8
+#endif
 #define MAGI_MAX_P 6
 #define MAGI_MAX_DEPTH 12   // checkpoint slots for the iterative NUTS U-turn checks
 #define MAGI_TAIL_THREADS 256
 #define MAGI_WAVE 64
+
+// a[d] for a runtime d without a runtime-indexed register array (which would live in scratch)
+#if MAGI_MAX_D == 4
+#define MAGI_SEL_D(a, d) (((d) == 0) ? (a)[0] : ((d) == 1) ? (a)[1] : ((d) == 2) ? (a)[2] : (a)[3])
+#else
+template <int N>
+__host__ __device__ __forceinline__ double sel_n(const double (&a)[N], int d) {
+    double v = a[N - 1];
+#pragma unroll
+    for (int k = N - 2; k >= 0; --k) v = (d == k) ? a[k] : v;
+    return v;
+}
+#define MAGI_SEL_D(a, d) sel_n(a, d)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Device-visible problem description (passed by value to kernels)
@@ -266,7 +282,8 @@ __device__ inline double rng_normal_elem(unsigned int e, unsigned int step, unsi
 // writes V_Q (fp64 exp/log are ~100-instruction sequences: keeping them out of the per-row
 // epilogues and out of the 1024-thread reduce is worth tens of microseconds per gradient).
 // ------------------------------------------------------------------------------------------
-enum ParOff { PAR_TH = 0, PAR_SGT = 8, PAR_LJT = 16, PAR_SIG2 = 24, PAR_SGS = 28, PAR_LJS = 32, PAR_LOG2PIS = 36,
+enum ParOff { PAR_TH = 0, PAR_SGT = 8, PAR_LJT = 16, PAR_SIG2 = 24, PAR_SGS = 24 + MAGI_MAX_D, PAR_LJS = 24 + 2 * MAGI_MAX_D,
+              PAR_LOG2PIS = 24 + 3 * MAGI_MAX_D,
               PAR_ULEAF = 56, PAR_UMERGE = 57 /* (unused) */,
               PAR_COUNT = 64 };
 
@@ -276,7 +293,7 @@ __device__ inline void compute_par_entry(const DevProblem& pb, int j, double pre
     const double sp = m_log(1.0 + e);          // magi_v2.py:318-319
     const double sg = e / (1.0 + e);           // d softplus / d pre (= 1/(1+exp(-pre)) up to rounding)
     if (j < pb.D) {
-        const double lb = (j == 0) ? pb.LB[0] : (j == 1) ? pb.LB[1] : (j == 2) ? pb.LB[2] : pb.LB[3];
+        const double lb = MAGI_SEL_D(pb.LB, j);
         const double s2 = sp + lb;
         par[PAR_SIG2 + j] = s2;
         par[PAR_SGS + j] = sg;
@@ -342,9 +359,11 @@ __device__ __forceinline__ double drift_jt_g(int drift, int d, const double* x, 
     switch (drift) {
 #ifdef MAGI_USER_DRIFT_HEADER
     case MAGI_DRIFT_USER: {
-        double c[MAGI_MAX_D] = {0.0, 0.0, 0.0, 0.0};
+        double c[MAGI_MAX_D];
+#pragma unroll
+        for (int k = 0; k < MAGI_MAX_D; ++k) c[k] = 0.0;
         user_drift_jt(x, th, g, c, nullptr);
-        return d == 0 ? c[0] : d == 1 ? c[1] : d == 2 ? c[2] : c[3];
+        return MAGI_SEL_D(c, d);
     }
 #endif
     case MAGI_DRIFT_SEIR3: {
@@ -640,7 +659,7 @@ __device__ inline FinalizeOut finalize_gradient(const DevProblem& pb, double* vb
         if (j < D) {
             const double s2 = par[PAR_SIG2 + j], sg = par[PAR_SGS + j];
             const double ssd = select_lane<K>(red, 2, MAGI_MAX_D, j);
-            const double nds = (j == 0) ? pb.N_ds[0] : (j == 1) ? pb.N_ds[1] : (j == 2) ? pb.N_ds[2] : pb.N_ds[3];
+            const double nds = MAGI_SEL_D(pb.N_ds, j);
             t3 = nds * par[PAR_LOG2PIS + j];
             t4 = ssd * (1.0 / s2);
             lj = par[PAR_LJS + j];

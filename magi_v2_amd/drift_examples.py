@@ -16,7 +16,18 @@ def lotka_volterra(t, X, thetas):
     return np.concatenate([thetas[0] * x - thetas[1] * x * y, thetas[3] * x * y - thetas[2] * y], axis=1)
 
 
-EXAMPLES = {"fhn": (fitzhugh_nagumo, 2, 3), "lotka_volterra": (lotka_volterra, 2, 4)}
+def protein_transduction(t, X, thetas):
+    """Protein signalling transduction (5 components S, dS, R, RS, Rpp; 6 parameters) -- the third benchmark of the MAGI paper."""
+    S, dS, R, RS, Rpp = (X[:, k:k + 1] for k in range(5))
+    k1, k2, k3, k4, V, Km = (thetas[k] for k in range(6))
+    return np.concatenate([-k1 * S - k2 * S * R + k3 * RS,
+                           k1 * S,
+                           -k2 * S * R + k3 * RS + V * Rpp / (Km + Rpp),
+                           k2 * S * R - k3 * RS - k4 * RS,
+                           k4 * RS - V * Rpp / (Km + Rpp)], axis=1)
+
+
+EXAMPLES = {"fhn": (fitzhugh_nagumo, 2, 3), "lotka_volterra": (lotka_volterra, 2, 4), "ptrans": (protein_transduction, 5, 6)}
 
 
 def rk4(f_vec, x0, thetas, T, n, substeps=20):

@@ -41,18 +41,19 @@ def library_for(drift, verbose: bool = False) -> str:
     with open(hdr, "w") as fh:
         fh.write(drift.header)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    wide = drift.D > 4                        # 5..8 components: wider per-point lane groups and parameter blocks
     objs, procs = [], []
     for src in _build.sources():
         base = os.path.basename(src)
         shared = os.path.join(_build.HERE, "build", base + ".o")
-        if base in _DRIFT_FREE and os.path.exists(shared) and not _build.needs_build():
+        if base in _DRIFT_FREE and not wide and os.path.exists(shared) and not _build.needs_build():
             objs.append(shared)
             continue
         obj = os.path.join(d, base + ".o")
         objs.append(obj)
         contract = [] if base == "build.hip" else ["-ffp-contract=on"]
         cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-function",
-               f'-DMAGI_USER_DRIFT_HEADER="{hdr}"'] + contract + ["-c", src, "-o", obj]
+               f'-DMAGI_USER_DRIFT_HEADER="{hdr}"'] + (["-DMAGI_MAX_D=8"] if wide else []) + contract + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

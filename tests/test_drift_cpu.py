@@ -55,8 +55,8 @@ def test_builtin_drifts_are_recognised_and_their_traced_jacobians_equal_the_orac
 
 
 def test_limits_and_untraceable_callables_fail_loudly():
-    with pytest.raises(NotImplementedError, match="D <= 4"):
-        drift.trace_drift(lambda t, X, th: X, 5, 2)
+    with pytest.raises(NotImplementedError, match="D <= 8"):
+        drift.trace_drift(lambda t, X, th: X, 9, 2)
     with pytest.raises(NotImplementedError, match="explicit use of t"):
         drift.trace_drift(lambda t, X, th: X * th[0] + t, 2, 1)
     with pytest.raises(ValueError, match="shape"):

@@ -22,9 +22,10 @@ def oracle_drift(f_vec):
 
 def make_problem(name, N=41, band=None, seed=0):
     f_vec, D, P = EXAMPLES[name]
-    truth = {"fhn": np.array([0.2, 0.2, 3.0]), "lotka_volterra": np.array([1.5, 1.0, 3.0, 1.0])}[name]
-    x0 = {"fhn": [-1.0, 1.0], "lotka_volterra": [1.0, 1.5]}[name]
-    I, X = rk4(f_vec, x0, truth, {"fhn": 20.0, "lotka_volterra": 8.0}[name], N)
+    truth = {"fhn": np.array([0.2, 0.2, 3.0]), "lotka_volterra": np.array([1.5, 1.0, 3.0, 1.0]),
+             "ptrans": np.array([0.07, 0.6, 0.05, 0.3, 0.017, 0.3])}[name]
+    x0 = {"fhn": [-1.0, 1.0], "lotka_volterra": [1.0, 1.5], "ptrans": [1.0, 0.0, 1.0, 0.0, 0.0]}[name]
+    I, X = rk4(f_vec, x0, truth, {"fhn": 20.0, "lotka_volterra": 8.0, "ptrans": 100.0}[name], N)
     rng = np.random.default_rng(seed)
     X_obs = X + rng.normal(0, 0.1, X.shape)
     X_obs[1::2] = np.nan                                                  # observations on every other grid point
@@ -44,7 +45,7 @@ def make_problem(name, N=41, band=None, seed=0):
     return eng, pr, Xhat, hp, truth
 
 
-@pytest.mark.parametrize("name,band", [("fhn", None), ("lotka_volterra", None), ("fhn", 6)])
+@pytest.mark.parametrize("name,band", [("fhn", None), ("lotka_volterra", None), ("fhn", 6), ("ptrans", None)])
 def test_user_drift_log_posterior_and_gradient_match_oracle(name, band):
     eng, pr, Xhat, hp, truth = make_problem(name, band=band)
     rng = np.random.default_rng(5)
@@ -120,4 +121,22 @@ def test_tiny_grid_runs_and_matches_oracle():
     _, _, otp, _, _ = orc.sample_chain(pr, Xhat, hp["sigma_sqs"], np.ones(4), 3, 5, seed=5, stale_cache=False, trace=trace)
     np.testing.assert_array_equal(eng.sampler_diag().leapfrogs_taken[0], [r.leapfrogs for _, r, _ in trace])
     np.testing.assert_allclose(tp_s[0], otp, rtol=1e-7, atol=1e-9)
+    eng.close()
+
+
+def test_five_component_system_chain_matches_oracle():
+    """More than four components (the protein-transduction benchmark, D = 5, P = 6): the specialised library is built with
+    eight component lanes per grid point; a NUTS chain still equals the oracle draw for draw."""
+    eng, pr, Xhat, hp, truth = make_problem("ptrans")
+    sp0, tp0 = host.softplus_inverse_inits(hp["sigma_sqs"], np.full(6, 0.2), pr.LB)
+    cfg = eng.default_cfg(num_results=3, num_burnin_steps=7, stale_cache=0)
+    eng.sampler_init(cfg, Xhat, sp0, tp0, seed=21)
+    eng.sampler_run(10)
+    Xs, sp, tp = eng.sampler_samples()
+    trace = []
+    oX, osp, otp, info, _ = orc.sample_chain(pr, Xhat, hp["sigma_sqs"], np.full(6, 0.2), 3, 7, seed=21, stale_cache=False, trace=trace)
+    np.testing.assert_array_equal(eng.sampler_diag().leapfrogs_taken[0], [r.leapfrogs for _, r, _ in trace])
+    np.testing.assert_allclose(tp[0], otp, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(sp[0], osp, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(Xs[0], oX, rtol=0, atol=1e-8 * np.abs(oX).max())
     eng.close()
