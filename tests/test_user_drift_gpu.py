@@ -140,3 +140,19 @@ def test_five_component_system_chain_matches_oracle():
     np.testing.assert_allclose(sp[0], osp, rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(Xs[0], oX, rtol=0, atol=1e-8 * np.abs(oX).max())
     eng.close()
+
+
+def test_five_component_system_through_the_api():
+    """MAGI_v2(...) -> initial_fit -> predict with the 5-component protein-transduction f_vec (one component never observed)."""
+    import magi_v2
+    from magi_v2_amd.drift_examples import protein_transduction
+    truth = np.array([0.07, 0.6, 0.05, 0.3, 0.017, 0.3])
+    ts, X = rk4(protein_transduction, [1.0, 0.0, 1.0, 0.0, 0.0], truth, 100.0, 26)
+    X_obs = X + np.random.default_rng(1).normal(0, 0.01, X.shape)
+    X_obs[:, 1] = np.nan                                        # the degraded-signal component is not observed
+    model = magi_v2.MAGI_v2(D_thetas=6, ts_obs=ts, X_obs=X_obs, bandsize=None, f_vec=protein_transduction)
+    model.initial_fit(discretization=1, hparam_iters=20, theta_init_iters=500)
+    assert model.C_d_invs.shape == (5, 51, 51) and np.isfinite(model.thetas_init).all() and np.isfinite(model.Xhat_init).all()
+    res = model.predict(num_results=20, num_burnin_steps=20, seed=3, stale_cache=False)
+    assert res["X_samps"].shape == (20, 51, 5) and res["thetas_samps"].shape == (20, 6)
+    assert np.isfinite(res["X_samps"]).all() and (res["thetas_samps"] > 0).all()
