@@ -84,7 +84,12 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int tix = (int)blockIdx.x - n_dec;
-    const int4 task = reinterpret_cast<const int4*>(pb.tasks)[tix];
+    // (the descriptor table is read-only for the lifetime of the matrices: fetched through the constant address space it is a
+    //  scalar load on its own counter, so waiting for it does not wait for the tile loads issued below and vice versa)
+    typedef const int __attribute__((address_space(4))) * const_int_ptr;
+    const_int_ptr tk = (const_int_ptr)(unsigned long long)(pb.tasks + 4 * (size_t)tix);
+    int4 task;
+    task.x = tk[0]; task.y = tk[1]; task.z = tk[2]; task.w = tk[3];
     // the wave's rows in chunks of 8, two chunks in flight (a0 / a1): 16 KB per wave on the wire while one chunk is in the ALUs.
     // tile loads need nothing but the block index: on the wire before the plan-dependent loads (except in the waves that derive theta')
     const double2* A = reinterpret_cast<const double2*>(pb.tiles + (size_t)tix * TB * TB + (size_t)((threadIdx.x >> 6) * ST_RW) * TB) + (threadIdx.x & 63);
