@@ -263,6 +263,7 @@ template <int DRIFT>
 __global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains ch, int parity) {
     __shared__ double res[PT_POINTS * PT_DSLOT * 4];
     __shared__ double redk[64 * PART_K];
+    __shared__ double s_mu[MAGI_MAX_D];
     // (flag and plan are fetched together and combined arithmetically: `a || b` would fetch b only after a has arrived --
     //  one more dependent round trip at the head of a 5 us kernel)
     const int all_done = ch.gctl->all_done;
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains c
     kernarg_prefetch<sizeof(DevProblem) + sizeof(DevChains) + sizeof(int)>();
     const int gate = all_done | (lp.active ^ 1) | lp.skip;
     if (gate != 0) return;
-    point_block<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, res, redk);
+    point_block<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, res, redk, s_mu);
 }
 
 // validation plan (magi_logpost_grad_fused / timing): slot 0 evaluates buffer 0 as is, no leapfrog

@@ -51,8 +51,10 @@ struct GridPoint {     // component d of grid index i of one chain (one lane)
         return o;
     }
 
+    // `mud` = mu[d], read by the caller from an LDS copy: selecting pb.mu[d] with a per-lane d makes the compiler spill the
+    // kernel-argument array to scratch and index it there -- a global-memory round trip in the middle of the finishing lane
     static __device__ __forceinline__ void finish(const DevProblem& pb, const DevChains& ch, const LeafPlan& lp, int cc, int i, int d, const Ops& o,
-                                                  const double* res /* [D][4] */, double* pk /* [PART_K] */) {
+                                                  const double* res /* [D][4] */, double mud, double* pk /* [PART_K] */) {
 #pragma unroll
         for (int k = 0; k < PART_K; ++k) pk[k] = 0.0;
         const int N = pb.N, dimp = pb.dimp;
@@ -66,9 +68,9 @@ struct GridPoint {     // component d of grid index i of one chain (one lane)
         for (int dd = 0; dd < D; ++dd) g2[dd] = 2.0 * (res[dd * 4 + TV_KF] - res[dd * 4 + TV_EX]);
         DR::jt(o.x, o.th, g2, jt, tp);
         // select this lane's component
-        double xd = o.x[0], fd = f[0], jtd = jt[0], mud = pb.mu[0];
+        double xd = o.x[0], fd = f[0], jtd = jt[0];
 #pragma unroll
-        for (int dd = 1; dd < D; ++dd) if (d == dd) { xd = o.x[dd]; fd = f[dd]; jtd = jt[dd]; mud = pb.mu[dd]; }
+        for (int dd = 1; dd < D; ++dd) if (d == dd) { xd = o.x[dd]; fd = f[dd]; jtd = jt[dd]; }
         const double hx = res[d * 4 + TV_HX], ex = res[d * 4 + TV_EX], etf = res[d * 4 + TV_ETF], kf = res[d * 4 + TV_KF];
         pk[PK_T12] = (xd - mud) * hx + fd * (kf - 2.0 * ex);
         if (d == 0) {
@@ -106,7 +108,7 @@ struct GridPoint {     // component d of grid index i of one chain (one lane)
 // All PT_THREADS threads of the block must call it.  res: PT_POINTS*PT_DSLOT*4 doubles, redk: 64*PART_K doubles of LDS.
 // Writes part[cc][k][blk].  `lp`: the chain's plan for this slot (active, not skip).
 template <int DRIFT>
-__device__ __forceinline__ void point_block(const DevProblem& pb, const DevChains& ch, const LeafPlan& lp, int cc, int blk, double* res, double* redk) {
+__device__ __forceinline__ void point_block(const DevProblem& pb, const DevChains& ch, const LeafPlan& lp, int cc, int blk, double* res, double* redk, double* s_mu /* MAGI_MAX_D */) {
     using GP = GridPoint<DRIFT>;
     constexpr int D = GP::D, TB = MAGI_TB;
     const unsigned t = threadIdx.x;
@@ -136,11 +138,15 @@ __device__ __forceinline__ void point_block(const DevProblem& pb, const DevChain
         }
         res[(pt * PT_DSLOT + d) * 4 + v] = sum;
     }
+    if (t == PT_THREADS - 1) {
+#pragma unroll
+        for (int k = 0; k < MAGI_MAX_D; ++k) s_mu[k] = pb.mu[k];       // (static indices: one thread copies the kernel-argument array)
+    }
     __syncthreads();
     if (t < 64) {
         double* pk = redk + (size_t)t * PART_K;
         if (fvalid) {
-            GP::finish(pb, ch, lp, cc, fi, fd, ops, res + fpt * PT_DSLOT * 4, pk);
+            GP::finish(pb, ch, lp, cc, fi, fd, ops, res + fpt * PT_DSLOT * 4, s_mu[fd], pk);
         } else {
 #pragma unroll
             for (int k = 0; k < PART_K; ++k) pk[k] = 0.0;
