@@ -114,7 +114,7 @@ __device__ __forceinline__ LeafPlan make_leaf_plan(const ChainCtl& c, unsigned l
 // (they complete slot parity ^ 1 ... i.e. the slot the point phase executed last, and write plan[parity]).
 template <int DRIFT>
 __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChains& ch, const SamplerCfgDev& cfg, int chain, int parity, int all_done,
-                                             double* sh /* 25*16 */, double* shs /* 24 */, ChainCtl* s_ctl, int* s_g, double* s_par /* PAR_COUNT */, double* s_ops /* OPS_COUNT * OPS_W */) {
+                                             double* sh /* 25*16 */, double* shs /* 24 */, ChainCtl* s_ctl, int* s_g, double* s_par /* PAR_COUNT */, double* s_ops /* OPS_COUNT * OPS_W */, double* s_cst /* 2 * MAGI_MAX_D */) {
     const int tid = threadIdx.x;
     MAGI_STAMP(ch.par, 8);
     // ONE round of loads with no dependence on anything: control state, the previous plan, the state's parameter block
@@ -141,6 +141,10 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
     else if (tid == PT_THREADS - 2) s_g[0] = ctl_w;
     else if (tid == PT_THREADS - 1) s_g[1] = ctl_w;
     if (tid >= 64 && tid < 64 + PAR_COUNT) s_par[tid - 64] = par_v;
+    if (tid == PT_THREADS - 3) {
+#pragma unroll
+        for (int k = 0; k < MAGI_MAX_D; ++k) { s_cst[k] = pb.N_ds[k]; s_cst[MAGI_MAX_D + k] = pb.LB[k]; }      // (static indices)
+    }
     reduce_prefetch_ops_store<OPS_PER>(ops_v, s_ops);
     MAGI_STAMP(ch.par, 2);
     __syncthreads();
@@ -191,7 +195,7 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
         if (leaf && tid == 192) shs[22] = m_log1p(-rng_uniform(lp.depth, lp.step_k, lp.chain_id, STREAM_MERGE, lp.seed));
         if (!leaf && tid == 64) shs[16] = cfg.anneal ? temperature(0, cfg.min_temp) : 1.0;
         // ---- add the streaming kernel's partial sums, finish the parameter entries -----------------------
-        const ReduceOut ro = leap_reduce<DRIFT>(pb, ch, chain, vb, par, s_par, lp, pre, sh, shs, s_ops);
+        const ReduceOut ro = leap_reduce<DRIFT>(pb, ch, chain, vb, par, s_par, lp, pre, sh, shs, s_ops, s_cst);
         MAGI_STAMP(par, 4);
         const double L = ro.L;
         const double u_leaf = shs[21], u_merge = shs[22];        // (published by the barriers inside leap_reduce)
@@ -438,7 +442,7 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
                     const double qn = q0[u] + eps * ph;
                     qw[e] = qn;
                     v.rhosub[e] = 0.0;
-                    if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par);
+                    if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par, true, s_cst + MAGI_MAX_D);
                 }
             }
         }

@@ -78,8 +78,9 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
         __shared__ int s_g[2];
         __shared__ double s_par[PAR_COUNT];
         __shared__ double s_ops[OPS_COUNT * OPS_W];
+        __shared__ double s_cst[2 * MAGI_MAX_D];
         const int chain = c0 + (int)blockIdx.x;
-        if (chain < ch.n_chains) decide_block<DRIFT>(pb, ch, cfg, chain, parity, all_done, dsh, dshs, &s_ctl, s_g, s_par, s_ops);
+        if (chain < ch.n_chains) decide_block<DRIFT>(pb, ch, cfg, chain, parity, all_done, dsh, dshs, &s_ctl, s_g, s_par, s_ops, s_cst);
         return;
     }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;

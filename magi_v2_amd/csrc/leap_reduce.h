@@ -124,7 +124,8 @@ __device__ __forceinline__ void reduce_prefetch_ops_store(const double (&tmp)[PE
 template <int DRIFT>
 __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const DevChains& ch, int chain, double* vb, double* par, const double* par_r,
                                                  const LeafPlan& lp, const double (&pre)[RedLayout<DRIFT>::PER_WAVE], double* sh, double* shs,
-                                                 const double* ops = nullptr /* LDS copy made by reduce_prefetch_ops, or null */) {
+                                                 const double* ops = nullptr /* LDS copy made by reduce_prefetch_ops, or null */,
+                                                 const double* cst = nullptr /* LDS: N_ds[MAX_D], LB[MAX_D], or null */) {
     using DR = DriftT<DRIFT>;
     constexpr int D = DR::D, P = DR::P;
     const int ND = pb.ND, dimp = pb.dimp;
@@ -167,7 +168,7 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
         const int jd = threadIdx.x - 128;
         double t3 = 0.0;
         if (jd < D) {
-            const double nds = MAGI_SEL_D(pb.N_ds, jd);
+            const double nds = cst ? cst[jd] : MAGI_SEL_D(pb.N_ds, jd);
             t3 = nds * m_log(2.0 * 3.141592653589793 * par_r[PAR_SIG2 + jd]);
         }
         t3 = row16_sum(t3);
@@ -198,7 +199,7 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
         if (j < D) {
             const double sg = par_r[PAR_SGS + j], sj = par_r[PAR_SIG2 + j];
             const double ssd = select_lane<K0 + 8>(red, 1, D, j);
-            const double nds = MAGI_SEL_D(pb.N_ds, j);
+            const double nds = cst ? cst[j] : MAGI_SEL_D(pb.N_ds, j);
             t4 = ssd * (1.0 / sj);
             lj = par_r[PAR_LJS + j];
             gj = -0.5 * (nds / sj - ssd / (sj * sj)) * sg + (1.0 - sg);
@@ -248,7 +249,7 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
             if (jj < D) {
                 const double sg = par_r[PAR_SGS + jj], sj = par_r[PAR_SIG2 + jj];
                 const double ssd = select_lane<K0 + 8>(red, 1, D, jj);
-                const double nds = MAGI_SEL_D(pb.N_ds, jj);
+                const double nds = cst ? cst[jj] : MAGI_SEL_D(pb.N_ds, jj);
                 gj = -0.5 * (nds / sj - ssd / (sj * sj)) * sg + (1.0 - sg);
             } else {
                 const double sg = par_r[PAR_SGT + (jj - D)];
@@ -258,7 +259,7 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
             const double phv = ops ? ops[(OPS_P + lp.cur) * OPS_W + jj] : ph[ND + jj], qv = ops ? ops[(OPS_Q + lp.cur) * OPS_W + jj] : q[ND + jj];
             const double qnx = next_entry_pre(phv, qv, lp.hs, lp.eps, gj);
             // the old entries are still needed by wave 0 -> park the new ones, publish after the barrier
-            compute_par_entry(pb, jj, qnx, sh + 21 * 16, false);      // parking block of 64 doubles behind block_sum's scratch
+            compute_par_entry(pb, jj, qnx, sh + 21 * 16, false, cst ? cst + MAGI_MAX_D : nullptr);      // parking block of 64 doubles behind block_sum's scratch
         }
     }
     __syncthreads();

@@ -288,12 +288,14 @@ enum ParOff { PAR_TH = 0, PAR_SGT = 8, PAR_LJT = 16, PAR_SIG2 = 24, PAR_SGS = 24
               PAR_COUNT = 64 };
 
 // entry j of the parameter block: j < D -> sigma_pre[j], else theta_pre[j - D]
-__device__ inline void compute_par_entry(const DevProblem& pb, int j, double pre, double* par, bool with_log2pis = true) {
+// lb_tab: optional LDS copy of pb.LB (a per-lane select on the kernel-argument array compiles into a scratch table = a global
+// round trip; the sampler's decision workgroup stages N_ds and LB in LDS once)
+__device__ inline void compute_par_entry(const DevProblem& pb, int j, double pre, double* par, bool with_log2pis = true, const double* lb_tab = nullptr) {
     const double e = m_exp(pre);
     const double sp = m_log(1.0 + e);          // magi_v2.py:318-319
     const double sg = e / (1.0 + e);           // d softplus / d pre (= 1/(1+exp(-pre)) up to rounding)
     if (j < pb.D) {
-        const double lb = MAGI_SEL_D(pb.LB, j);
+        const double lb = lb_tab ? lb_tab[j] : MAGI_SEL_D(pb.LB, j);
         const double s2 = sp + lb;
         par[PAR_SIG2 + j] = s2;
         par[PAR_SGS + j] = sg;
