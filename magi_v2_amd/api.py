@@ -7,7 +7,7 @@ CPU implementation of that path in this package: without the library or a GPU th
 What differs from the reference, deliberately:
   * ``f_vec`` is a built-in drift name or a numpy-compatible callable (TensorFlow is not a dependency).  A
     callable that equals a compiled-in drift uses the hand-written kernels; any other one is traced with
-    sympy and the kernels are compiled for it (drift.py, jit.py; D <= 8, P <= 6).
+    sympy and the kernels are compiled for it (drift.py, jit.py; D <= 8, P <= 8).
   * hyper-parameters are fitted on the GPU (``magi_fit_hparams``: the reference's GP marginal
     likelihood + priors + Adam, magi_v2.py:538-691, restated -- TFP itself is not available, so this
     step is parity-unpinned); ``hparams=`` / ``hparam_iters=0`` bypass it.

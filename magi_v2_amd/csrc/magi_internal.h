@@ -14,7 +14,9 @@
 #ifndef MAGI_MAX_D
 #define MAGI_MAX_D 4        // compiled-in drifts have D <= 4, P <= 5; a library built for a traced drift with 5..8 components sets 8
 #endif
-#define MAGI_MAX_P 6
+#ifndef MAGI_MAX_P
+#define MAGI_MAX_P 6        // a library built for a traced drift with 7 or 8 parameters sets 8
+#endif
 #define MAGI_MAX_DEPTH 12   // checkpoint slots for the iterative NUTS U-turn checks
 #define MAGI_TAIL_THREADS 256
 #define MAGI_WAVE 64
@@ -165,7 +167,7 @@ constexpr int MAGI_TB = 128;  // block edge of the packed single-phase operators
 enum TileKind { TK_FH = 0, TK_FK = 1, TK_FE = 2 };
 enum TileVec { TV_HX = 0, TV_EX = 1, TV_ETF = 2, TV_KF = 3 };
 
-constexpr int PART_K = 24;   // partial sums per workgroup and chain: t12, ss[D], tp[P], pp, 4 x (dA, dB)
+constexpr int PART_K = (1 + MAGI_MAX_D + MAGI_MAX_P + 1 + 8 + 3) / 4 * 4 < 24 ? 24 : (1 + MAGI_MAX_D + MAGI_MAX_P + 1 + 8 + 3) / 4 * 4;   // per workgroup and chain: t12, ss[D], tp[P], pp, 4 x (dA, dB)
 
 struct DevChains {
     double* vec;          // [n_chains][V_COUNT][dimp]
@@ -401,9 +403,12 @@ __device__ __forceinline__ void drift_tt_g_acc(int drift, const double (&x)[MAGI
     double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0, o4 = 0.0;
 #ifdef MAGI_USER_DRIFT_HEADER
     if (drift == MAGI_DRIFT_USER) {
-        double t[MAGI_MAX_P] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double t[MAGI_MAX_P];
+#pragma unroll
+        for (int k = 0; k < MAGI_MAX_P; ++k) t[k] = 0.0;
         user_drift_jt(x, th, g, nullptr, t);
-        out[0] += t[0]; out[1] += t[1]; out[2] += t[2]; out[3] += t[3]; out[4] += t[4]; out[5] += t[5];
+#pragma unroll
+        for (int k = 0; k < MAGI_MAX_P; ++k) out[k] += t[k];
         return;
     }
 #endif

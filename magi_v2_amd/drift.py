@@ -12,8 +12,8 @@ arrays (slicing, arithmetic, ``np.sum / np.concatenate / np.reshape / np.stack``
   sampler's kernels are compiled for it by ``magi_v2_amd.jit`` (hipcc, gfx950) into a specialised library.
 
 Callables that agree with a compiled-in drift (SEIR-3 of vignette.ipynb cell 3, SEIR-4, SIRW of
-test_magi_script.py:19-45) use the hand-written kernels of the base library.  Limits: D <= 8, P <= 6 (the
-per-workgroup partial-sum layout; 5..8 components use a build with wider per-point lanes), autonomous systems (``t`` may be passed but must not be used), drifts
+test_magi_script.py:19-45) use the hand-written kernels of the base library.  Limits: D <= 8, P <= 8 (the
+per-workgroup partial-sum layout; more than 4 components / 6 parameters use a build with wider lanes and blocks), autonomous systems (``t`` may be passed but must not be used), drifts
 expressible with elementwise arithmetic and sympy-known functions."""
 from __future__ import annotations
 
@@ -23,7 +23,7 @@ from typing import Callable, List, Optional, Tuple
 
 import numpy as np
 
-MAX_D, MAX_P = 8, 6        # more than 4 components: the specialised library is built with -DMAGI_MAX_D=8
+MAX_D, MAX_P = 8, 8        # more than 4 components / 6 parameters: the specialised library is built with -DMAGI_MAX_D=8 / -DMAGI_MAX_P=8
 BUILTIN_IDS = {"seir3": 0, "seir4": 1, "sirw": 2}
 USER_ID = 3
 

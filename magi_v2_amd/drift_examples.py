@@ -27,7 +27,15 @@ def protein_transduction(t, X, thetas):
                            k4 * RS - V * Rpp / (Km + Rpp)], axis=1)
 
 
-EXAMPLES = {"fhn": (fitzhugh_nagumo, 2, 3), "lotka_volterra": (lotka_volterra, 2, 4), "ptrans": (protein_transduction, 5, 6)}
+def competition_7(t, X, thetas):
+    """Two-species competition with self-limitation and immigration: 7 parameters (exercises builds with more than 6)."""
+    x, y = X[:, 0:1], X[:, 1:2]
+    a, b, c, d, e, f, g = (thetas[k] for k in range(7))
+    return np.concatenate([a * x - b * x * y - e * x ** 2, d * x * y - c * y - f * y ** 2 + g * x], axis=1)
+
+
+EXAMPLES = {"fhn": (fitzhugh_nagumo, 2, 3), "lotka_volterra": (lotka_volterra, 2, 4), "ptrans": (protein_transduction, 5, 6),
+            "competition7": (competition_7, 2, 7)}
 
 
 def rk4(f_vec, x0, thetas, T, n, substeps=20):

@@ -41,7 +41,7 @@ def library_for(drift, verbose: bool = False) -> str:
     with open(hdr, "w") as fh:
         fh.write(drift.header)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    wide = drift.D > 4                        # 5..8 components: wider per-point lane groups and parameter blocks
+    wide = drift.D > 4 or drift.P > 6         # wider per-point lane groups / parameter blocks than the base build's
     objs, procs = [], []
     for src in _build.sources():
         base = os.path.basename(src)
@@ -53,7 +53,7 @@ def library_for(drift, verbose: bool = False) -> str:
         objs.append(obj)
         contract = [] if base == "build.hip" else ["-ffp-contract=on"]
         cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-function",
-               f'-DMAGI_USER_DRIFT_HEADER="{hdr}"'] + (["-DMAGI_MAX_D=8"] if wide else []) + contract + ["-c", src, "-o", obj]
+               f'-DMAGI_USER_DRIFT_HEADER="{hdr}"'] + ((["-DMAGI_MAX_D=8"] if drift.D > 4 else []) + (["-DMAGI_MAX_P=8"] if drift.P > 6 else [])) + contract + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -23,9 +23,10 @@ def oracle_drift(f_vec):
 def make_problem(name, N=41, band=None, seed=0):
     f_vec, D, P = EXAMPLES[name]
     truth = {"fhn": np.array([0.2, 0.2, 3.0]), "lotka_volterra": np.array([1.5, 1.0, 3.0, 1.0]),
-             "ptrans": np.array([0.07, 0.6, 0.05, 0.3, 0.017, 0.3])}[name]
-    x0 = {"fhn": [-1.0, 1.0], "lotka_volterra": [1.0, 1.5], "ptrans": [1.0, 0.0, 1.0, 0.0, 0.0]}[name]
-    I, X = rk4(f_vec, x0, truth, {"fhn": 20.0, "lotka_volterra": 8.0, "ptrans": 100.0}[name], N)
+             "ptrans": np.array([0.07, 0.6, 0.05, 0.3, 0.017, 0.3]),
+             "competition7": np.array([1.5, 1.0, 3.0, 1.0, 0.1, 0.05, 0.2])}[name]
+    x0 = {"fhn": [-1.0, 1.0], "lotka_volterra": [1.0, 1.5], "ptrans": [1.0, 0.0, 1.0, 0.0, 0.0], "competition7": [1.0, 1.5]}[name]
+    I, X = rk4(f_vec, x0, truth, {"fhn": 20.0, "lotka_volterra": 8.0, "ptrans": 100.0, "competition7": 8.0}[name], N)
     rng = np.random.default_rng(seed)
     X_obs = X + rng.normal(0, 0.1, X.shape)
     X_obs[1::2] = np.nan                                                  # observations on every other grid point
@@ -45,7 +46,7 @@ def make_problem(name, N=41, band=None, seed=0):
     return eng, pr, Xhat, hp, truth
 
 
-@pytest.mark.parametrize("name,band", [("fhn", None), ("lotka_volterra", None), ("fhn", 6), ("ptrans", None)])
+@pytest.mark.parametrize("name,band", [("fhn", None), ("lotka_volterra", None), ("fhn", 6), ("ptrans", None), ("competition7", None)])
 def test_user_drift_log_posterior_and_gradient_match_oracle(name, band):
     eng, pr, Xhat, hp, truth = make_problem(name, band=band)
     rng = np.random.default_rng(5)
@@ -156,3 +157,18 @@ def test_five_component_system_through_the_api():
     res = model.predict(num_results=20, num_burnin_steps=20, seed=3, stale_cache=False)
     assert res["X_samps"].shape == (20, 51, 5) and res["thetas_samps"].shape == (20, 6)
     assert np.isfinite(res["X_samps"]).all() and (res["thetas_samps"] > 0).all()
+
+
+def test_seven_parameter_system_chain_matches_oracle():
+    """More than six parameters (P = 7): the specialised library is built with wider parameter blocks."""
+    eng, pr, Xhat, hp, truth = make_problem("competition7")
+    sp0, tp0 = host.softplus_inverse_inits(hp["sigma_sqs"], np.ones(7), pr.LB)
+    cfg = eng.default_cfg(num_results=3, num_burnin_steps=6, stale_cache=0)
+    eng.sampler_init(cfg, Xhat, sp0, tp0, seed=31)
+    eng.sampler_run(9)
+    Xs, sp, tp = eng.sampler_samples()
+    trace = []
+    oX, osp, otp, info, _ = orc.sample_chain(pr, Xhat, hp["sigma_sqs"], np.ones(7), 3, 6, seed=31, stale_cache=False, trace=trace)
+    np.testing.assert_array_equal(eng.sampler_diag().leapfrogs_taken[0], [r.leapfrogs for _, r, _ in trace])
+    np.testing.assert_allclose(tp[0], otp, rtol=1e-7, atol=1e-9)
+    eng.close()
