@@ -201,9 +201,14 @@ __device__ inline void gemm_store_tile(double* lds, long sk, const double (&reg)
     }
 }
 
-__global__ __launch_bounds__(256) void k_gemm_f64(GemmArgs g) {
+#ifndef MAGI_GEMM_OCC
+#define MAGI_GEMM_OCC 2      // 250 VGPRs, two workgroups per CU: one stages while the other issues MFMAs (1 -> 0.53, 2 -> 0.76 of the fp64 MFMA peak at N = 8192)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAGI_GEMM_OCC, MAGI_GEMM_OCC))) void k_gemm_f64(GemmArgs g) {
     __shared__ double As[GK * GP], Bs[GK * GP];
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    // kmode 2 tiles get longer k ranges with growing m0: dispatch the long ones first so the short ones fill the tail
+    const int by = (g.kmode == 2) ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    const int m0 = by * GT, n0 = blockIdx.x * GT;
     if (g.lower_only && m0 + GT - 1 < n0) return;
     const double* A = g.A + (long)blockIdx.z * g.batchA;
     const double* B = g.B + (long)blockIdx.z * g.batchB;
@@ -595,16 +600,19 @@ int potrf_status(Linalg& la, const char* what) {
 }
 
 // defer_status: only enqueue (no host synchronisation); the caller asks potrf_status later
-int potrf(Linalg& la, double* A, const char* what, bool defer_status = false) {
+// status_slot: which of the two status words of `la` records a failed pivot (a deferred caller may have two factorisations
+// in flight on the stream)
+int potrf(Linalg& la, double* A, const char* what, bool defer_status = false, int status_slot = 0) {
     magi_handle* h = la.h;
     const int N = la.N, NB = 128;
-    MAGI_HIP_CHECK(h, hipMemsetAsync(la.status, 0xFF, sizeof(int), la.s));          // -1
+    int* status = la.status + status_slot;
+    MAGI_HIP_CHECK(h, hipMemsetAsync(status, 0xFF, sizeof(int), la.s));          // -1
     const size_t lds = (size_t)DG_LDS_DOUBLES * sizeof(double);
     for (int j0 = 0, jb = 0; j0 < N; j0 += NB, ++jb) {
         const int n = std::min(NB, N - j0);
         double* Ajj = A + (size_t)j0 * N + j0;
         prof_begin(la.s);
-        hipLaunchKernelGGL(k_diag_chol_inv, dim3(1), dim3(256), lds, la.s, Ajj, (long)N, n, la.dinv + (size_t)jb * 128 * 128, la.status, j0);
+        hipLaunchKernelGGL(k_diag_chol_inv, dim3(1), dim3(256), lds, la.s, Ajj, (long)N, n, la.dinv + (size_t)jb * 128 * 128, status, j0);
         prof_end(la.s, BC_DIAG, (double)n * n * n);        // n^3/3 factor + 2 n^3/3 inverse
         const int M = N - j0 - n;
         if (M <= 0) break;
@@ -684,8 +692,8 @@ int lauum_tt(Linalg& la, const double* T, double* out) {
 }
 
 // A (SPD, overwritten) -> out = A^-1
-int spd_inverse(Linalg& la, double* A, double* out, const char* what) {
-    int rc = potrf(la, A, what);
+int spd_inverse(Linalg& la, double* A, double* out, const char* what, bool defer_status = false, int status_slot = 0) {
+    int rc = potrf(la, A, what, defer_status, status_slot);
     if (rc) return rc;
     if ((rc = trtri(la, A))) return rc;
     return lauum_tt(la, A, out);
@@ -696,7 +704,7 @@ int linalg_init(Linalg& la, magi_handle* h, int N) {
     const int nb = (N + 127) / 128;
     MAGI_HIP_CHECK(h, hipMalloc(&la.dinv, (size_t)nb * 128 * 128 * sizeof(double)));
     MAGI_HIP_CHECK(h, hipMalloc(&la.panel, std::max((size_t)N * 128, (size_t)N * N / 2 + 128 * 128) * sizeof(double)));
-    MAGI_HIP_CHECK(h, hipMalloc(&la.status, sizeof(int)));
+    MAGI_HIP_CHECK(h, hipMalloc(&la.status, 2 * sizeof(int)));
     MAGI_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_diag_chol_inv), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS_DOUBLES * (int)sizeof(double)));
     return MAGI_OK;
 }
@@ -945,51 +953,93 @@ int magi_build_matrices_device(magi_handle* h, const double* I, int N, int D, co
     for (int d = 0; d < D; ++d)
         if (!(phi1[d] > 0.0) || !(phi2[d] > 0.0)) return magi_fail(h, MAGI_E_BADARG, "phi1 and phi2 must be positive");
     const size_t nn = (size_t)N * N;
-    DevBuf dI, dKap, dP, dPP, dCinv, dM, dKinv;
+    // The D components are independent: each gets a stream and a work space (Kappa, p_Kappa, Kappa_pp, Cholesky scratch), so
+    // the one-workgroup diagonal-block kernels and the thin panels of one component run under the GEMMs of the others and
+    // small grids (64 tiles per GEMM at N = 1024) fill the GPU together.  W < D work spaces when memory is short: component
+    // d then follows component d - W on the same stream.
+    DevBuf dI, dCinv, dM, dKinv;
     MAGI_HIP_CHECK(h, dI.alloc(N));
-    MAGI_HIP_CHECK(h, dKap.alloc(nn));
-    MAGI_HIP_CHECK(h, dP.alloc(nn));
-    MAGI_HIP_CHECK(h, dPP.alloc(nn));
     MAGI_HIP_CHECK(h, dCinv.alloc(nn * D));
     MAGI_HIP_CHECK(h, dM.alloc(nn * D));
     MAGI_HIP_CHECK(h, dKinv.alloc(nn * D));
     MAGI_HIP_CHECK(h, hipMemcpy(dI.p, I, sizeof(double) * N, hipMemcpyHostToDevice));
-    Linalg la;
-    int rc = linalg_init(la, h, N);
-    if (rc) { linalg_free(la); return rc; }
+    MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    struct Work { DevBuf Kap, P, PP; Linalg la{}; hipStream_t stream = nullptr; };
+    int W = D;
+    {
+        size_t free_b = 0, total_b = 0;
+        const size_t per = (3 * nn + std::max((size_t)N * 128, nn / 2 + 128 * 128) + (size_t)((N + 127) / 128) * 128 * 128) * sizeof(double);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            W = (int)std::max<size_t>(1, std::min<size_t>((size_t)D, (free_b / 10 * 9) / per));
+        if (g_prof.on || getenv("MAGI_BUILD_SERIAL")) W = 1;
+    }
+    std::vector<Work> ws(W);
+    int rc = MAGI_OK;
+    auto cleanup = [&]() {
+        for (auto& w : ws) { linalg_free(w.la); if (w.stream) (void)hipStreamDestroy(w.stream); }
+    };
+    for (int k = 0; k < W && rc == MAGI_OK; ++k) {
+        Work& w = ws[k];
+        hipError_t e = w.Kap.alloc(nn);
+        if (e == hipSuccess) e = w.P.alloc(nn);
+        if (e == hipSuccess) e = w.PP.alloc(nn);
+        if (e == hipSuccess) e = hipStreamCreate(&w.stream);
+        if (e != hipSuccess) { rc = magi_fail(h, MAGI_E_HIP, std::string("build setup: ") + hipGetErrorString(e)); break; }
+        rc = linalg_init(w.la, h, N);
+        w.la.s = w.stream;
+    }
+    if (rc) { cleanup(); return rc; }
+    int* status = nullptr;                          // pinned, so the read-backs below do not stall the host between components
+    if (hipHostMalloc(reinterpret_cast<void**>(&status), (size_t)2 * D * sizeof(int)) != hipSuccess) { cleanup(); return magi_fail(h, MAGI_E_HIP, "build: pinned status"); }
+    for (int k = 0; k < 2 * D; ++k) status[k] = -1;
+    hipStream_t keep = h->stream;
     for (int d = 0; d < D && rc == MAGI_OK; ++d) {
+        Work& w = ws[d % W];
+        h->stream = w.stream;                       // launch_matern and the element-wise helpers launch on the handle's stream
         double* Cd = dCinv.p + nn * d;
         double* Md = dM.p + nn * d;
         double* Kd = dKinv.p + nn * d;
-        rc = launch_matern(h, dI.p, N, phi1[d], phi2[d], nu, dKap.p, dP.p, dPP.p);
+        rc = launch_matern(h, dI.p, N, phi1[d], phi2[d], nu, w.Kap.p, w.P.p, w.PP.p);
         // C^-1 = Kappa^-1 (Kappa is consumed)                              magi_v2.py:818, 126
-        if (!rc) rc = spd_inverse(la, dKap.p, Cd, "Kappa");
+        if (!rc) rc = spd_inverse(w.la, w.Kap.p, Cd, "Kappa", true, 0);
         // m = p_Kappa Kappa^-1                                              magi_v2.py:819
         if (!rc) {
             GemmArgs g{};
-            g.A = dP.p; g.sAm = N; g.sAk = 1;
+            g.A = w.P.p; g.sAm = N; g.sAk = 1;
             g.B = Cd; g.sBn = 1; g.sBk = N;
             g.C = Md; g.ldc = N; g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 0.0;
-            rc = launch_gemm(h, h->stream, g);
+            rc = launch_gemm(h, w.stream, g);
         }
         // K = Kappa_pp - m Kappa_p = Kappa_pp + m p_Kappa  (Kappa_p = -p_Kappa, :805, :820)
         if (!rc) {
             GemmArgs g{};
             g.A = Md; g.sAm = N; g.sAk = 1;
-            g.B = dP.p; g.sBn = 1; g.sBk = N;
-            g.C = dPP.p; g.ldc = N; g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 1.0;
-            rc = launch_gemm(h, h->stream, g);
+            g.B = w.P.p; g.sBn = 1; g.sBk = N;
+            g.C = w.PP.p; g.ldc = N; g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 1.0;
+            rc = launch_gemm(h, w.stream, g);
         }
         if (!rc) {
             dim3 grid((N + 31) / 32, (N + 31) / 32);
-            hipLaunchKernelGGL(k_symmetrize, grid, dim3(32, 32), 0, h->stream, dPP.p, N);
-            rc = spd_inverse(la, dPP.p, Kd, "K_d");                        // magi_v2.py:128
+            hipLaunchKernelGGL(k_symmetrize, grid, dim3(32, 32), 0, w.stream, w.PP.p, N);
+            rc = spd_inverse(w.la, w.PP.p, Kd, "K_d", true, 1);              // magi_v2.py:128
         }
+        // the two pivot words of this component, read back in stream order before the work space is reused
+        if (!rc && hipMemcpyAsync(&status[(size_t)2 * d], w.la.status, 2 * sizeof(int), hipMemcpyDeviceToHost, w.stream) != hipSuccess)
+            rc = magi_fail(h, MAGI_E_HIP, "build: status readback");
     }
-    hipError_t se = hipStreamSynchronize(h->stream);
-    linalg_free(la);
+    h->stream = keep;
+    hipError_t se = hipSuccess;
+    for (auto& w : ws) { hipError_t e = hipStreamSynchronize(w.stream); if (se == hipSuccess) se = e; }
+    cleanup();
+    std::vector<int> st(status, status + 2 * D);
+    (void)hipHostFree(status);
     if (rc) return rc;
     if (se != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("build: ") + hipGetErrorString(se));
+    for (int d = 0; d < D; ++d)
+        for (int k = 0; k < 2; ++k)
+            if (st[(size_t)2 * d + k] >= 0)
+                return magi_fail(h, MAGI_E_NOTSPD, std::string("Cholesky of ") + (k ? "K_d" : "Kappa") + " (component " + std::to_string(d) +
+                                 "): non-positive pivot at index " + std::to_string(st[(size_t)2 * d + k]));
     if (C_inv) MAGI_HIP_CHECK(h, hipMemcpy(C_inv, dCinv.p, nn * D * sizeof(double), hipMemcpyDeviceToHost));
     if (m) MAGI_HIP_CHECK(h, hipMemcpy(m, dM.p, nn * D * sizeof(double), hipMemcpyDeviceToHost));
     if (K_inv) MAGI_HIP_CHECK(h, hipMemcpy(K_inv, dKinv.p, nn * D * sizeof(double), hipMemcpyDeviceToHost));

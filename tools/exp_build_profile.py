@@ -19,6 +19,6 @@ for k, (f, ms, calls) in prof.items():
     tf = f / (ms * 1e-3) / 1e12 if ms > 0 and f > 0 else 0.0
     rows.append({"class": k, "calls": calls, "gflop": round(f / 1e9, 1), "ms": round(ms, 2), "tflops": round(tf, 2), "frac_fp64_mfma_peak": round(tf / PEAK, 3)})
 tot_f = sum(p[0] for p in prof.values()); tot_ms = sum(p[1] for p in prof.values())
-out = {"N": N, "D": D, "wall_s_profiled": round(wall, 3), "sum_ms": round(tot_ms, 1), "tflops_overall": round(tot_f / (tot_ms * 1e-3) / 1e12, 2),
-       "algorithmic_5N3D_tflops": round(5.0 * N ** 3 * D / (tot_ms * 1e-3) / 1e12, 2), "peak_tflops": PEAK, "classes": rows}
+out = {"N": N, "D": D, "wall_s_profiled": round(wall, 3), "sum_ms": round(tot_ms, 1), "tflops_overall": round(tot_f / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else None,
+       "algorithmic_5N3D_tflops": round(5.0 * N ** 3 * D / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else None, "peak_tflops": PEAK, "classes": rows}
 print(json.dumps(out, indent=1))
