@@ -102,12 +102,20 @@ struct MaternArgs {
     double logA;               // log(phi1 2^{1-nu} / Gamma(nu))
     double diag_pp;            // nu phi1 / (phi2^2 (nu - 1))
     BesselConsts bc;
+    int rows;                  // grid rows per workgroup (64, fewer on small grids: an entry costs microseconds of dependent
+                               // fp64 arithmetic, so a small matrix wants one entry per thread rather than 16)
+    const double* dyn;         // non-null: phi1, c, logA, diag_pp come from device memory (FitDyn below) -- the hyper-parameter
+                               // fit replays one captured graph per Adam step, so its launch arguments cannot change
 };
 
 // 64 x 64 tile per 256-thread workgroup; the two 64-entry slices of the time grid staged in LDS
+// layout of the per-component device block of the hyper-parameter fit (doubles)
+enum FitDyn { FD_RAW = 0, FD_M = 3, FD_V = 6, FD_PV = 9 /* phi1, phi2, sigma^2 */, FD_C = 12, FD_LOGA, FD_DIAGPP, FD_SHIFT, FD_COUNT };
+
 __global__ __launch_bounds__(256) void k_matern(MaternArgs a) {
     __shared__ double ts[64], tt[64];
-    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    if (a.dyn) { a.phi1 = a.dyn[FD_PV]; a.c = a.dyn[FD_C]; a.logA = a.dyn[FD_LOGA]; a.diag_pp = a.dyn[FD_DIAGPP]; }
+    const int i0 = blockIdx.y * a.rows, j0 = blockIdx.x * 64;
     if (threadIdx.x < 64) {
         const int i = i0 + threadIdx.x;
         ts[threadIdx.x] = (i < a.N) ? a.I[i] : 0.0;
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(256) void k_matern(MaternArgs a) {
     }
     __syncthreads();
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int r = ty; r < 64; r += 4) {
+    for (int r = ty; r < a.rows; r += 4) {
         const int i = i0 + r, j = j0 + tx;
         if (i >= a.N || j >= a.N) continue;
         double kap, pk, kpp;
@@ -322,8 +330,9 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
         S[i * DG_LD + j] = v;
     }
     __syncthreads();
+    const int nsb = (n + 31) >> 5, nl = 32 * nsb;          // live 32-wide sub-blocks (the identity padding behind them factors to itself)
 
-    for (int kb = 0; kb < 4; ++kb) {
+    for (int kb = 0; kb < nsb; ++kb) {
         const int c0 = 32 * kb;
         // ---- 1. diagonal sub-block: factor + inverse in the registers of wave 0 (lane = row, then lane = column) ----
         if (wave == 0) {
@@ -371,11 +380,11 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
         }
         __syncthreads();
         if (bad >= 0) break;
-        if (kb == 3) break;
+        if (kb == nsb - 1) break;
         // ---- 2. rows below: L21 = A21 * inv(L11)^T, one thread per row ------------------------------------------------
         {
             const int i = c0 + 32 + tid;
-            if (i < 128) {
+            if (i < nl) {
                 double a[32], o[32];
 #pragma unroll
                 for (int k = 0; k < 32; ++k) a[k] = S[i * DG_LD + c0 + k];
@@ -393,7 +402,7 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
         __syncthreads();
         // ---- 3. trailing update A22 -= L21 L21^T on the lower triangle, 2 x 2 tiles ------------------------------------------
         {
-            const int m0 = c0 + 32, mt = (128 - m0) >> 1;           // tiles per side
+            const int m0 = c0 + 32, mt = (nl - m0) >> 1;           // tiles per side
             for (int t = tid; t < mt * mt; t += 256) {
                 const int bi = t / mt, bj = t - bi * mt;
                 if (bj > bi) continue;
@@ -419,7 +428,7 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
     }
     // ---- off-diagonal blocks of the inverse: X_ij = -X_ii * sum_{k=j}^{i-1} L_ik X_kj  (block rows in order) -----------------------
     auto Xf = [&](int i, int j) -> double { return i == j ? dinv[i] : (i > j ? S[j * DG_LD + i] : 0.0); };
-    for (int bi = 1; bi < 4; ++bi)
+    for (int bi = 1; bi < nsb; ++bi)
         for (int bj = 0; bj < bi; ++bj) {
             double c[2][2];
             dg_tile_gemm((bi - bj) * 32,
@@ -477,9 +486,10 @@ __global__ void k_symmetrize(double* A, int N) {             // A = (A + A^T)/2,
 // device pieces: S = Kappa + (sigma^2 + jitter) I, log det from the Cholesky factor, alpha = S^-1 r,
 // and the trace terms of d loglik / d(phi1, phi2, sigma^2) = 1/2 tr((alpha alpha^T - S^-1) dS/d.)
 // =============================================================================================
-__global__ void k_fit_shift(const double* __restrict__ Kap, double* __restrict__ S, int N, double shift) {
+__global__ void k_fit_shift(const double* __restrict__ Kap, double* __restrict__ S, int N, double shift, const double* __restrict__ dyn) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t)N * N) return;
+    if (dyn) shift = dyn[FD_SHIFT];
     const int i = (int)(e / N), j = (int)(e - (size_t)i * N);
     S[e] = Kap[e] + (i == j ? shift : 0.0);
 }
@@ -534,6 +544,64 @@ __global__ __launch_bounds__(256) void k_fit_final(const double* __restrict__ pa
         for (int k = 0; k < 5; ++k) v[k] += part[(size_t)b * 5 + k];
     block_sum<5>(v, sh);
     if (threadIdx.x < 5) out[threadIdx.x] = v[threadIdx.x];
+}
+
+// The scalar tail of one Adam step of one component, on the device so that a fit never waits for the host:
+// log likelihood and gradient from the reduced sums, TruncatedNormal priors, softplus chain rule, Adam update (tf_keras
+// defaults), next hyper-parameters and the Matern constants derived from them.  (reference: magi_v2.py:611-691)
+struct FitStepArgs {
+    double* dyn;               // [FD_COUNT]
+    int* ist;                  // [0] step t (1-based)  [1] failed pivot index (-1: none, sticky)  [2] step of the failure
+    const double* out;         // [6] sums of k_fit_final + log-diagonal sum
+    const int* status;         // pivot word of this step's Cholesky
+    double* trace;             // [iters]: D (loglik + log prior) of the parameters the step started from
+    int N, D;
+    double nu, lgam_nu, mu_phi2, sd_phi2, sig_loc, lr, jitter;
+};
+
+__device__ inline void fit_derive(double* dyn, double nu, double lgam_nu, double jitter) {
+    const double p1 = dyn[FD_PV], p2 = dyn[FD_PV + 1], s2 = dyn[FD_PV + 2];
+    dyn[FD_C] = sqrt(2.0 * nu) / p2;
+    dyn[FD_LOGA] = log(p1) + (1.0 - nu) * log(2.0) - lgam_nu;
+    dyn[FD_DIAGPP] = nu * p1 / ((p2 * p2) * (nu - 1.0));
+    dyn[FD_SHIFT] = s2 + jitter;
+}
+
+__global__ void k_fit_step(FitStepArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double* dyn = a.dyn;
+    const int t = a.ist[0];
+    if (t == 0) {                                      // first launch: hyper-parameters from the raw variables
+        for (int k = 0; k < 3; ++k) dyn[FD_PV + k] = log1p(exp(dyn[FD_RAW + k]));
+        fit_derive(dyn, a.nu, a.lgam_nu, a.jitter);
+        a.ist[0] = 1;
+        return;
+    }
+    if (a.ist[1] >= 0) return;
+    if (a.status[0] >= 0) { a.ist[1] = a.status[0]; a.ist[2] = t; return; }
+    const double D = (double)a.D, sD = sqrt(D);
+    const double p1 = dyn[FD_PV], p2 = dyn[FD_PV + 1], s2 = dyn[FD_PV + 2];
+    const double* o = a.out;
+    const double logdet = 2.0 * o[5];
+    const double ll = -0.5 * o[3] - 0.5 * logdet - 0.5 * a.N * log(2.0 * 3.141592653589793);
+    const double g3[3] = {0.5 * o[0] / p1, 0.5 * o[1] / p2, 0.5 * (o[4] - o[2])};
+    const double sc[3] = {1000.0 * sD, a.sd_phi2 * sD, 1000.0 * sD};
+    const double z[3] = {(p1 - 1e-4) / sc[0], (p2 - a.mu_phi2) / sc[1], (s2 - a.sig_loc) / sc[2]};
+    const double lp = -0.5 * (z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
+    a.trace[t - 1] = D * (ll + lp);
+    const double b1 = 0.9, b2 = 0.999, eps = 1e-7;
+    const double al = a.lr * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t));
+    for (int k = 0; k < 3; ++k) {
+        const double raw = dyn[FD_RAW + k];
+        const double g = -D * (g3[k] - z[k] / sc[k]) * (1.0 / (1.0 + exp(-raw)));
+        const double m = b1 * dyn[FD_M + k] + (1.0 - b1) * g;
+        const double v = b2 * dyn[FD_V + k] + (1.0 - b2) * g * g;
+        const double nraw = raw - al * m / (sqrt(v) + eps);
+        dyn[FD_M + k] = m; dyn[FD_V + k] = v; dyn[FD_RAW + k] = nraw;
+        dyn[FD_PV + k] = log1p(exp(nraw));
+    }
+    fit_derive(dyn, a.nu, a.lgam_nu, a.jitter);
+    a.ist[0] = t + 1;
 }
 
 struct Linalg {
@@ -737,14 +805,17 @@ BesselConsts bessel_consts(double nu) {
     return bc;
 }
 
-int launch_matern(magi_handle* h, const double* dI, int N, double phi1, double phi2, double nu, double* dK, double* dP, double* dPP) {
+int launch_matern(magi_handle* h, const double* dI, int N, double phi1, double phi2, double nu, double* dK, double* dP, double* dPP, const double* dyn = nullptr) {
     MaternArgs a{};
+    a.dyn = dyn;
     a.I = dI; a.Kappa = dK; a.pKappa = dP; a.Kappapp = dPP; a.N = N;
     a.phi1 = phi1; a.nu = nu; a.c = std::sqrt(2.0 * nu) / phi2;
     a.logA = std::log(phi1) + (1.0 - nu) * std::log(2.0) - std::lgamma(nu);
     a.diag_pp = nu * phi1 / ((phi2 * phi2) * (nu - 1.0));
     a.bc = bessel_consts(nu);
-    dim3 grid((N + 63) / 64, (N + 63) / 64);
+    a.rows = 64;
+    while (a.rows > 4 && (long)((N + 63) / 64) * ((N + a.rows - 1) / a.rows) < 1024) a.rows /= 2;
+    dim3 grid((N + 63) / 64, (N + a.rows - 1) / a.rows);
     prof_begin(h->stream);
     hipLaunchKernelGGL(k_matern, grid, dim3(256), 0, h->stream, a);
     prof_end(h->stream, BC_MATERN, 0.0);
@@ -770,17 +841,22 @@ struct FitWork {          // one component: its own work space and stream, so th
     int* host_status = nullptr;      // pinned
     hipStream_t stream = nullptr;
     int N = 0, nblk = 0;
+    DevBuf dyn, trace;               // device-resident Adam loop: FitDyn block, per-step objective
+    int* ist = nullptr;              // device: step counter, sticky failure
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
 };
 
 // enqueue one evaluation of component `w` on ITS stream (w.la.s); nothing here waits for the device
-int fit_issue(magi_handle* h, FitWork& w, double phi1, double phi2, double sig2, double nu, double jitter) {
+// dyn != nullptr: hyper-parameters come from the component's device block and nothing is read back (graph capture)
+int fit_issue(magi_handle* h, FitWork& w, double phi1, double phi2, double sig2, double nu, double jitter, const double* dyn = nullptr) {
     const int N = w.N;
     hipStream_t keep = h->stream;
     h->stream = w.la.s;                       // the helpers below launch on the handle's stream
-    int rc = launch_matern(h, w.I.p, N, phi1, phi2, nu, w.Kap.p, w.pK.p, w.Kpp.p);
+    int rc = launch_matern(h, w.I.p, N, phi1, phi2, nu, w.Kap.p, w.pK.p, w.Kpp.p, dyn);
     const size_t nn = (size_t)N * N;
     if (rc == MAGI_OK) {
-        hipLaunchKernelGGL(k_fit_shift, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, w.Kap.p, w.S.p, N, sig2 + jitter);
+        hipLaunchKernelGGL(k_fit_shift, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, w.Kap.p, w.S.p, N, sig2 + jitter, dyn);
         rc = potrf(w.la, w.S.p, "GP marginal covariance", true);
     }
     if (rc == MAGI_OK) {
@@ -795,7 +871,7 @@ int fit_issue(magi_handle* h, FitWork& w, double phi1, double phi2, double sig2,
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) rc = magi_fail(h, MAGI_E_HIP, std::string("fit launch: ") + hipGetErrorString(e));
     }
-    if (rc == MAGI_OK) {
+    if (rc == MAGI_OK && !dyn) {
         hipError_t e = hipMemcpyAsync(w.host, w.out.p, 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(w.host_status, w.la.status, sizeof(int), hipMemcpyDeviceToHost, h->stream);
         if (e != hipSuccess) rc = magi_fail(h, MAGI_E_HIP, std::string("fit readback: ") + hipGetErrorString(e));
@@ -850,6 +926,9 @@ int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const
             linalg_free(w.la);
             if (w.host) (void)hipHostFree(w.host);
             if (w.host_status) (void)hipHostFree(w.host_status);
+            if (w.exec) (void)hipGraphExecDestroy(w.exec);
+            if (w.graph) (void)hipGraphDestroy(w.graph);
+            if (w.ist) (void)hipFree(w.ist);
             if (w.stream) (void)hipStreamDestroy(w.stream);
         }
     };
@@ -880,6 +959,70 @@ int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const
     // raw variables, order [phi1(D), phi2(D), sig2(D)] ; Adam state
     std::vector<double> raw(3 * D), m(3 * D, 0.0), v(3 * D, 0.0), grad(3 * D);
     for (int d = 0; d < D; ++d) { raw[d] = softplus_inv(phi1[d]); raw[D + d] = softplus_inv(phi2[d]); raw[2 * D + d] = softplus_inv(sig2[d]); }
+    if (!getenv("MAGI_FIT_HOST_LOOP")) {
+        // Device-resident loop: one Adam step of one component = one captured graph (Matern blocks -> Cholesky -> inverse ->
+        // reductions -> k_fit_step) whose inputs live in the component's FitDyn block; the host replays it `iters` times on
+        // the component's stream and synchronises once at the end.
+        g_prof.on = false;                                            // (its events would synchronise inside the capture)
+        const double lgam = std::lgamma(nu);
+        for (int d = 0; d < D && rc == MAGI_OK; ++d) {
+            FitWork& w = ws[d];
+            hipError_t e = hipSuccess;
+            auto chk = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+            chk(w.dyn.alloc(FD_COUNT)); chk(w.trace.alloc((size_t)std::max(iters, 1)));
+            chk(hipMalloc(reinterpret_cast<void**>(&w.ist), 4 * sizeof(int)));
+            double init[FD_COUNT] = {0.0};
+            for (int k = 0; k < 3; ++k) init[FD_RAW + k] = raw[(size_t)k * D + d];
+            const int ist0[4] = {0, -1, 0, 0};
+            if (e == hipSuccess) chk(hipMemcpy(w.dyn.p, init, sizeof(init), hipMemcpyHostToDevice));
+            if (e == hipSuccess) chk(hipMemcpy(w.ist, ist0, sizeof(ist0), hipMemcpyHostToDevice));
+            if (e == hipSuccess) chk(hipMemset(w.trace.p, 0, (size_t)std::max(iters, 1) * sizeof(double)));
+            if (e != hipSuccess) { rc = magi_fail(h, MAGI_E_HIP, std::string("fit setup: ") + hipGetErrorString(e)); break; }
+            FitStepArgs sa{};
+            sa.dyn = w.dyn.p; sa.ist = w.ist; sa.out = w.out.p; sa.status = w.la.status; sa.trace = w.trace.p; sa.N = N; sa.D = D;
+            sa.nu = nu; sa.lgam_nu = lgam; sa.mu_phi2 = mu_phi2[d]; sa.sd_phi2 = sd_phi2[d]; sa.sig_loc = sig_loc[d]; sa.lr = lr; sa.jitter = jitter;
+            hipLaunchKernelGGL(k_fit_step, dim3(1), dim3(64), 0, w.stream, sa);          // t = 0: derive the first hyper-parameters
+            chk(hipStreamBeginCapture(w.stream, hipStreamCaptureModeThreadLocal));
+            if (e == hipSuccess) {
+                rc = fit_issue(h, w, 1.0, 1.0, 1.0, nu, jitter, w.dyn.p);
+                hipLaunchKernelGGL(k_fit_step, dim3(1), dim3(64), 0, w.stream, sa);
+                chk(hipStreamEndCapture(w.stream, &w.graph));
+            }
+            if (e == hipSuccess && rc == MAGI_OK) chk(hipGraphInstantiate(&w.exec, w.graph, nullptr, nullptr, 0));
+            if (e != hipSuccess && rc == MAGI_OK) rc = magi_fail(h, MAGI_E_HIP, std::string("fit graph: ") + hipGetErrorString(e));
+        }
+        for (int t = 1; t <= iters && rc == MAGI_OK; ++t)
+            for (int d = 0; d < D && rc == MAGI_OK; ++d)
+                if (hipGraphLaunch(ws[d].exec, ws[d].stream) != hipSuccess) rc = magi_fail(h, MAGI_E_HIP, "fit graph launch");
+        std::vector<double> tr((size_t)std::max(iters, 1) * D, 0.0);
+        for (int d = 0; d < D && rc == MAGI_OK; ++d) {
+            FitWork& w = ws[d];
+            hipError_t e = hipStreamSynchronize(w.stream);
+            double fin[FD_COUNT]; int ist[4] = {0, -1, 0, 0};
+            if (e == hipSuccess) e = hipMemcpy(fin, w.dyn.p, sizeof(fin), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(ist, w.ist, sizeof(ist), hipMemcpyDeviceToHost);
+            if (e == hipSuccess && iters > 0) e = hipMemcpy(tr.data() + (size_t)d * iters, w.trace.p, (size_t)iters * sizeof(double), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { rc = magi_fail(h, MAGI_E_HIP, std::string("fit: ") + hipGetErrorString(e)); break; }
+            if (ist[1] >= 0) {
+                rc = magi_fail(h, MAGI_E_NOTSPD, "Cholesky of GP marginal covariance (component " + std::to_string(d) + ", Adam step " + std::to_string(ist[2]) +
+                               "): non-positive pivot at index " + std::to_string(ist[1]));
+                break;
+            }
+            for (int k = 0; k < 3; ++k) raw[(size_t)k * D + d] = fin[FD_RAW + k];
+        }
+        for (auto& w : ws) (void)hipStreamSynchronize(w.stream);
+        cleanup();
+        if (rc) return rc;
+        if (loss_trace)
+            for (int t = 0; t < iters; ++t) {
+                double loss = 0.0;
+                for (int d = 0; d < D; ++d) loss -= tr[(size_t)d * iters + t];
+                loss_trace[t] = loss;
+            }
+        for (int d = 0; d < D; ++d) { phi1[d] = softplus(raw[d]); phi2[d] = softplus(raw[D + d]); sig2[d] = softplus(raw[2 * D + d]); }
+        return MAGI_OK;
+    }
+    // host loop (MAGI_FIT_HOST_LOOP=1): the same arithmetic with the scalar tail and Adam on the host, one synchronisation per step
     const double sD = std::sqrt((double)D);
     const double b1 = 0.9, b2 = 0.999, eps = 1e-7;
     std::vector<double> pv(3 * D);
