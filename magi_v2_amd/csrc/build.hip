@@ -185,28 +185,43 @@ struct GemmArgs {
 
 constexpr int GT = 128, GK = 16, GP = 129;   // odd pitch: the k-fast staging stores of a 16-lane group hit 16 distinct bank pairs
 
-__device__ inline void gemm_load_tile(const double* base, long sm, long sk, int m0, int k0, int Mlim, int Klim, double (&reg)[8]) {
-    // 128 x 16 tile = 2048 doubles, 8 per thread; walk the unit-stride dimension fastest
+// 128 x 16 operand tile = 2048 doubles, 8 per thread, walking the unit-stride dimension fastest.  A thread's 8 elements are
+// p + i * di with p per thread (loop-invariant: row/column of the thread) and di uniform, so a load costs an SGPR offset and a
+// predicate -- written as base[gm * sm + gk * sk] per element it cost three quarter-rate 64-bit multiplies, ~1300 VALU cycles
+// per K step next to 4096 MFMA cycles.
+struct TileWalk {
+    const double* p;     // element (m_t, k_t) of the tile at k0 = 0
+    long di;             // element stride between a thread's consecutive elements
+    int m_t, k_t, dm, dk, lds0, dlds;
+};
+
+__device__ __forceinline__ TileWalk gemm_tile_walk(const double* base, long sm, long sk, int m0) {
+    TileWalk w;
     const bool kfast = (sk == 1);
+    const int t = threadIdx.x;
+    w.m_t = kfast ? (t >> 4) : (t & 127);
+    w.k_t = kfast ? (t & 15) : (t >> 7);
+    w.dm = kfast ? 16 : 0;
+    w.dk = kfast ? 0 : 2;
+    w.di = kfast ? 16 * sm : 2 * sk;
+    w.p = base + (long)(m0 + w.m_t) * sm + (long)w.k_t * sk;
+    w.lds0 = w.k_t * GP + w.m_t;
+    w.dlds = kfast ? 16 : 2 * GP;
+    return w;
+}
+
+__device__ __forceinline__ void gemm_load_tile(const TileWalk& w, long sk, int m0, int k0, int Mlim, int Klim, double (&reg)[8]) {
+    const double* q = w.p + (long)k0 * sk;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int idx = threadIdx.x + 256 * i;
-        const int m = kfast ? (idx >> 4) : (idx & 127);
-        const int k = kfast ? (idx & 15) : (idx >> 7);
-        const int gm = m0 + m, gk = k0 + k;
-        reg[i] = (gm < Mlim && gk < Klim) ? base[(long)gm * sm + (long)gk * sk] : 0.0;
+        const bool ok = (m0 + w.m_t + i * w.dm < Mlim) && (k0 + w.k_t + i * w.dk < Klim);
+        reg[i] = ok ? q[i * w.di] : 0.0;
     }
 }
 
-__device__ inline void gemm_store_tile(double* lds, long sk, const double (&reg)[8]) {
-    const bool kfast = (sk == 1);
+__device__ __forceinline__ void gemm_store_tile(double* lds, const TileWalk& w, const double (&reg)[8]) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = threadIdx.x + 256 * i;
-        const int m = kfast ? (idx >> 4) : (idx & 127);
-        const int k = kfast ? (idx & 15) : (idx >> 7);
-        lds[k * GP + m] = reg[i];
-    }
+    for (int i = 0; i < 8; ++i) lds[w.lds0 + i * w.dlds] = reg[i];
 }
 
 #ifndef MAGI_GEMM_OCC
@@ -236,18 +251,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAGI_GEMM_O
         for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
     double ra[8], rb[8];
+    const TileWalk wa = gemm_tile_walk(A, g.sAm, g.sAk, m0), wb = gemm_tile_walk(B, g.sBn, g.sBk, n0);
     if (kbeg < kend) {
-        gemm_load_tile(A, g.sAm, g.sAk, m0, kbeg, g.M, kend, ra);
-        gemm_load_tile(B, g.sBn, g.sBk, n0, kbeg, g.N, kend, rb);
+        gemm_load_tile(wa, g.sAk, m0, kbeg, g.M, kend, ra);
+        gemm_load_tile(wb, g.sBk, n0, kbeg, g.N, kend, rb);
     }
     for (int k0 = kbeg; k0 < kend; k0 += GK) {
         __syncthreads();
-        gemm_store_tile(As, g.sAk, ra);
-        gemm_store_tile(Bs, g.sBk, rb);
+        gemm_store_tile(As, wa, ra);
+        gemm_store_tile(Bs, wb, rb);
         __syncthreads();
         if (k0 + GK < kend) {
-            gemm_load_tile(A, g.sAm, g.sAk, m0, k0 + GK, g.M, kend, ra);
-            gemm_load_tile(B, g.sBn, g.sBk, n0, k0 + GK, g.N, kend, rb);
+            gemm_load_tile(wa, g.sAk, m0, k0 + GK, g.M, kend, ra);
+            gemm_load_tile(wb, g.sBk, n0, k0 + GK, g.N, kend, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < GK / 4; ++kk) {
