@@ -210,18 +210,62 @@ __device__ __forceinline__ TileWalk gemm_tile_walk(const double* base, long sm, 
     return w;
 }
 
+// INTERIOR: the whole 128 x 16 tile lies inside the operand (uniform per workgroup and K step): no predicates, no branches
+template <bool INTERIOR>
 __device__ __forceinline__ void gemm_load_tile(const TileWalk& w, long sk, int m0, int k0, int Mlim, int Klim, double (&reg)[8]) {
     const double* q = w.p + (long)k0 * sk;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const bool ok = (m0 + w.m_t + i * w.dm < Mlim) && (k0 + w.k_t + i * w.dk < Klim);
-        reg[i] = ok ? q[i * w.di] : 0.0;
+        if (INTERIOR) {
+            reg[i] = q[i * w.di];
+        } else {
+            const bool ok = (m0 + w.m_t + i * w.dm < Mlim) && (k0 + w.k_t + i * w.dk < Klim);
+            reg[i] = ok ? q[i * w.di] : 0.0;
+        }
     }
 }
 
 __device__ __forceinline__ void gemm_store_tile(double* lds, const TileWalk& w, const double (&reg)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) lds[w.lds0 + i * w.dlds] = reg[i];
+}
+
+template <bool INTERIOR>
+__device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, const double* A, const double* B, int m0, int n0, int kbeg, int kend,
+                                              double* As, double* Bs, d4 (&acc)[4][4]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int lr = lane & 15, lk = lane >> 4;
+    double ra[8], rb[8];
+    const TileWalk wa = gemm_tile_walk(A, g.sAm, g.sAk, m0), wb = gemm_tile_walk(B, g.sBn, g.sBk, n0);
+    if (kbeg < kend) {
+        gemm_load_tile<INTERIOR>(wa, g.sAk, m0, kbeg, g.M, kend, ra);
+        gemm_load_tile<INTERIOR>(wb, g.sBk, n0, kbeg, g.N, kend, rb);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+        __syncthreads();
+        gemm_store_tile(As, wa, ra);
+        gemm_store_tile(Bs, wb, rb);
+        __syncthreads();
+        if (k0 + GK < kend) {
+            gemm_load_tile<INTERIOR>(wa, g.sAk, m0, k0 + GK, g.M, kend, ra);
+            gemm_load_tile<INTERIOR>(wb, g.sBk, n0, k0 + GK, g.N, kend, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < GK / 4; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = As[(kk * 4 + lk) * GP + wm + i * 16 + lr];
+                b[i] = Bs[(kk * 4 + lk) * GP + wn + i * 16 + lr];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
 }
 
 #ifndef MAGI_GEMM_OCC
@@ -250,36 +294,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAGI_GEMM_O
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
-    double ra[8], rb[8];
-    const TileWalk wa = gemm_tile_walk(A, g.sAm, g.sAk, m0), wb = gemm_tile_walk(B, g.sBn, g.sBk, n0);
-    if (kbeg < kend) {
-        gemm_load_tile(wa, g.sAk, m0, kbeg, g.M, kend, ra);
-        gemm_load_tile(wb, g.sBk, n0, kbeg, g.N, kend, rb);
-    }
-    for (int k0 = kbeg; k0 < kend; k0 += GK) {
-        __syncthreads();
-        gemm_store_tile(As, wa, ra);
-        gemm_store_tile(Bs, wb, rb);
-        __syncthreads();
-        if (k0 + GK < kend) {
-            gemm_load_tile(wa, g.sAk, m0, k0 + GK, g.M, kend, ra);
-            gemm_load_tile(wb, g.sBk, n0, k0 + GK, g.N, kend, rb);
-        }
-#pragma unroll
-        for (int kk = 0; kk < GK / 4; ++kk) {
-            double a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = As[(kk * 4 + lk) * GP + wm + i * 16 + lr];
-                b[i] = Bs[(kk * 4 + lk) * GP + wn + i * 16 + lr];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    }
+    // interior workgroups (all 128 rows of both operand tiles exist, whole K steps) run the loop without predicates
+    const bool interior = (m0 + GT <= g.M) && (n0 + GT <= g.N) && ((kend - kbeg) % GK == 0);
+    if (interior) gemm_mainloop<true>(g, A, B, m0, n0, kbeg, kend, As, Bs, acc);
+    else gemm_mainloop<false>(g, A, B, m0, n0, kbeg, kend, As, Bs, acc);
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
     for (int i = 0; i < 4; ++i)
