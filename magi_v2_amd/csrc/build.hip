@@ -268,6 +268,45 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, const double* A
     }
 }
 
+// C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg.  FULL: the 128 x 128 tile lies inside C, no
+// predicates -- with a branch per element the compiler waits for ALL outstanding memory operations (vmcnt counts stores too) in
+// front of every store.  Read-modify-write (beta != 0) loads the 16 values of a row block before its 16 stores: element by
+// element the load -> store order must be kept, 64 dependent round trips per thread, several times the MFMA time of a K = 128
+// update.
+template <bool FULL>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, double* C, int m0, int n0, const d4 (&acc)[4][4]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int lr = lane & 15, lk = lane >> 4;
+    double* c0 = C + (long)(m0 + wm + lk) * g.ldc + n0 + wn + lr;          // element (i, j, r) at c0 + (16 i + 4 r) ldc + 16 j
+    const int mrel = m0 + wm + lk, nrel = n0 + wn + lr;
+    if (g.beta == 0.0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (FULL || (mrel + 16 * i + 4 * r < g.M && nrel + 16 * j < g.N)) c0[(long)(16 * i + 4 * r) * g.ldc + 16 * j] = g.alpha * acc[i][j][r];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double c[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    c[j][r] = (FULL || (mrel + 16 * i + 4 * r < g.M && nrel + 16 * j < g.N)) ? c0[(long)(16 * i + 4 * r) * g.ldc + 16 * j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (FULL || (mrel + 16 * i + 4 * r < g.M && nrel + 16 * j < g.N))
+                        c0[(long)(16 * i + 4 * r) * g.ldc + 16 * j] = g.alpha * acc[i][j][r] + g.beta * c[j][r];
+        }
+    }
+}
+
 #ifndef MAGI_GEMM_OCC
 #define MAGI_GEMM_OCC 2      // 250 VGPRs, two workgroups per CU: one stages while the other issues MFMAs (1 -> 0.53, 2 -> 0.76 of the fp64 MFMA peak at N = 8192)
 #endif
@@ -284,10 +323,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAGI_GEMM_O
     if (g.kmode == 1) kbeg = (max(m0, n0) / GK) * GK;
     else if (g.kmode == 2) kend = min(g.K, m0 + GT);
     else if (g.kmode == 3) kbeg = (n0 / GK) * GK;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int lr = lane & 15, lk = lane >> 4;
-
     d4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -298,21 +333,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAGI_GEMM_O
     const bool interior = (m0 + GT <= g.M) && (n0 + GT <= g.N) && ((kend - kbeg) % GK == 0);
     if (interior) gemm_mainloop<true>(g, A, B, m0, n0, kbeg, kend, As, Bs, acc);
     else gemm_mainloop<false>(g, A, B, m0, n0, kbeg, kend, As, Bs, acc);
-    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm + i * 16 + lk + 4 * r;
-                const int n = n0 + wn + j * 16 + lr;
-                if (m < g.M && n < g.N) {
-                    double* p = C + (long)m * g.ldc + n;
-                    const double v = g.alpha * acc[i][j][r];
-                    *p = (g.beta == 0.0) ? v : v + g.beta * (*p);
-                }
-            }
+    if ((m0 + GT <= g.M) && (n0 + GT <= g.N)) gemm_epilogue<true>(g, C, m0, n0, acc);
+    else gemm_epilogue<false>(g, C, m0, n0, acc);
 }
 
 // =============================================================================================
