@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAGI_GEMM_O
 // identity so no loop carries bounds.
 // =============================================================================================
 constexpr int DG_LD = 129;
-constexpr int DG_LDS_DOUBLES = 128 * DG_LD + 128 + 32 * 33 + 2;
+constexpr int DG_LDS_DOUBLES = 128 * DG_LD + 128 + 3 * 32 * 33 + 2;      // 158 480 bytes of the CU's 160 KB
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -360,10 +360,13 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 
 // C (32 x 32, thread tile 2 x 2) = sum over k of  a(i, k) * b(k, j)  with accessors (no bounds: the caller passes K)
+// (K is a multiple of 32; unrolled by 8 so that eight iterations' LDS reads are in flight -- one at a time the loop is a chain of
+//  LDS latencies, 250 cycles per k)
 template <class FA, class FB>
-__device__ __forceinline__ void dg_tile_gemm(int K, FA a, FB b, double (&c)[2][2]) {
+__device__ __forceinline__ void dg_tile_gemm(int K, FA a, FB b, double (&c)[2][2], bool accumulate = false) {
     const int ti = (threadIdx.x >> 4) * 2, tj = (threadIdx.x & 15) * 2;
-    c[0][0] = c[0][1] = c[1][0] = c[1][1] = 0.0;
+    if (!accumulate) c[0][0] = c[0][1] = c[1][0] = c[1][1] = 0.0;
+#pragma unroll 8
     for (int k = 0; k < K; ++k) {
         const double a0 = a(ti, k), a1 = a(ti + 1, k), b0 = b(k, tj), b1 = b(k, tj + 1);
         c[0][0] = fma(a0, b0, c[0][0]); c[0][1] = fma(a0, b1, c[0][1]);
@@ -371,21 +374,44 @@ __device__ __forceinline__ void dg_tile_gemm(int K, FA a, FB b, double (&c)[2][2
     }
 }
 
+#ifdef MAGI_DIAG_STAMPS      // dev: s_memtime at the phase boundaries of k_diag_chol_inv, printed by thread 0
+#define DG_STAMP(i) do { if (threadIdx.x == 0) dg_st[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DG_STAMP_PRINT() do { if (threadIdx.x == 0 && block_row0 == 0) { printf("diag stamps (cycles from start):"); for (int q = 1; q < 16; ++q) printf(" %d:%lld", q, (long long)(dg_st[q] - dg_st[0])); printf("\n"); } } while (0)
+#else
+#define DG_STAMP(i) do {} while (0)
+#define DG_STAMP_PRINT() do {} while (0)
+#endif
 __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int n, double* Linv /* [128][128] */, int* status, int block_row0) {
+#ifdef MAGI_DIAG_STAMPS
+    unsigned long long dg_st[16] = {0};
+#endif
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* S = lds;                               // [128][DG_LD]
     double* dinv = lds + 128 * DG_LD;              // diagonal of the inverse
     double* T = dinv + 128;                        // [32][33]
-    int& bad = *reinterpret_cast<int*>(T + 32 * 33);
+    double* T1 = T + 32 * 33;                      // dense copies of two diagonal blocks of the inverse
+    double* T2 = T1 + 32 * 33;
+    int& bad = *reinterpret_cast<int*>(T2 + 32 * 33);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) bad = -1;
-    for (int e = tid; e < 128 * 128; e += 256) {
-        const int i = e >> 7, j = e & 127;
-        double v = (i == j) ? 1.0 : 0.0;           // identity padding
-        if (i < n && j < n) v = (j <= i) ? A[(long)i * lda + j] : 0.0;
-        S[i * DG_LD + j] = v;
+    DG_STAMP(0);
+    // (eight unconditional loads in flight per thread, from clamped addresses: `S[..] = cond ? A[..] : pad` in a plain loop is a
+    //  load -> LDS store chain, one memory round trip per element)
+    for (int e0 = tid; e0 < 128 * 128; e0 += 256 * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u, i = e >> 7, j = e & 127;
+            v[u] = A[(long)min(i, n - 1) * lda + min(j, n - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u, i = e >> 7, j = e & 127;
+            S[i * DG_LD + j] = (i < n && j < n) ? ((j <= i) ? v[u] : 0.0) : ((i == j) ? 1.0 : 0.0);      // identity padding
+        }
     }
     __syncthreads();
+    DG_STAMP(1);
     const int nsb = (n + 31) >> 5, nl = 32 * nsb;          // live 32-wide sub-blocks (the identity padding behind them factors to itself)
 
     for (int kb = 0; kb < nsb; ++kb) {
@@ -399,12 +425,21 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
 #pragma unroll
             for (int c = 0; c < 32; ++c) if (c > r) d[c] = 0.0;
             int fail = -1;
+            double myrd = 0.0;                                                            // lane k keeps 1 / L_kk
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
                 const double piv = readlane_f64(d[k], k);
                 if (!(piv > 0.0) && fail < 0) fail = c0 + k;                              // uniform; also catches NaN
-                const double dk = sqrt(piv);
-                d[k] = (r == k) ? dk : d[k] / dk;
+                // 1/sqrt(piv): v_rsq_f64 (~23 bits) + two Newton steps, then sqrt = piv * y with one correction.  The library
+                // sqrt followed by a division is ~70 dependent fp64 instructions per column, 60 % of this phase.
+                double y = __builtin_amdgcn_rsq(piv);
+                const double hp = 0.5 * piv;
+                y = fma(y, fma(-hp * y, y, 0.5), y);
+                y = fma(y, fma(-hp * y, y, 0.5), y);
+                double dk = piv * y;
+                dk = fma(fma(-dk, dk, piv), 0.5 * y, dk);
+                if (r == k) myrd = y;
+                d[k] = (r == k) ? dk : d[k] * y;
 #pragma unroll
                 for (int j = k + 1; j < 32; ++j) {
                     const double ljk = readlane_f64(d[k], j);
@@ -419,8 +454,7 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
                 double sacc = 0.0;
 #pragma unroll
                 for (int k = 0; k < i; ++k) sacc = fma(readlane_f64(d[k], i), x[k], sacc);
-                const double lii = readlane_f64(d[i], i);
-                x[i] = (i < r) ? 0.0 : ((i == r) ? 1.0 : -sacc) / lii;
+                x[i] = (i < r) ? 0.0 : ((i == r) ? 1.0 : -sacc) * readlane_f64(myrd, i);
             }
             if (lane < 32) {
 #pragma unroll
@@ -435,6 +469,7 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
             }
         }
         __syncthreads();
+        DG_STAMP(2 + 3 * kb);
         if (bad >= 0) break;
         if (kb == nsb - 1) break;
         // ---- 2. rows below: L21 = A21 * inv(L11)^T, one thread per row ------------------------------------------------
@@ -456,12 +491,15 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
             }
         }
         __syncthreads();
+        DG_STAMP(3 + 3 * kb);
         // ---- 3. trailing update A22 -= L21 L21^T on the lower triangle, 2 x 2 tiles ------------------------------------------
         {
             const int m0 = c0 + 32, mt = (nl - m0) >> 1;           // tiles per side
-            for (int t = tid; t < mt * mt; t += 256) {
-                const int bi = t / mt, bj = t - bi * mt;
-                if (bj > bi) continue;
+            for (int t = tid; t < mt * (mt + 1) / 2; t += 256) {           // lower tiles only: t = bi (bi + 1) / 2 + bj
+                int bi = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                while (bi * (bi + 1) / 2 > t) --bi;
+                while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+                const int bj = t - bi * (bi + 1) / 2;
                 const int i = m0 + 2 * bi, j = m0 + 2 * bj;
                 double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
 #pragma unroll 8
@@ -477,6 +515,7 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
             }
         }
         __syncthreads();
+        DG_STAMP(4 + 3 * kb);
     }
     if (bad >= 0) {
         if (tid == 0) atomicCAS(status, -1, block_row0 + bad);
@@ -487,14 +526,25 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
     for (int bi = 1; bi < nsb; ++bi)
         for (int bj = 0; bj < bi; ++bj) {
             double c[2][2];
-            dg_tile_gemm((bi - bj) * 32,
+            // the diagonal blocks X_jj, X_ii live as a transposed triangle + a separate diagonal (Xf): dense copies, so that the
+            // product loops below are plain LDS reads the compiler can keep eight deep in flight
+            for (int e = tid; e < 32 * 32; e += 256) {
+                const int i = e >> 5, j = e & 31;
+                T1[i * 33 + j] = Xf(32 * bj + i, 32 * bj + j);
+                T2[i * 33 + j] = Xf(32 * bi + i, 32 * bi + j);
+            }
+            __syncthreads();
+            dg_tile_gemm(32,
                          [&](int i, int k) { return S[(32 * bi + i) * DG_LD + 32 * bj + k]; },
-                         [&](int k, int j) { return Xf(32 * bj + k, 32 * bj + j); }, c);
+                         [&](int k, int j) { return T1[k * 33 + j]; }, c);
+            dg_tile_gemm((bi - bj - 1) * 32,
+                         [&](int i, int k) { return S[(32 * bi + i) * DG_LD + 32 * bj + 32 + k]; },
+                         [&](int k, int j) { return S[(32 * bj + j) * DG_LD + 32 * bj + 32 + k]; }, c, true);
             const int ti = (tid >> 4) * 2, tj = (tid & 15) * 2;
             T[ti * 33 + tj] = c[0][0]; T[ti * 33 + tj + 1] = c[0][1]; T[(ti + 1) * 33 + tj] = c[1][0]; T[(ti + 1) * 33 + tj + 1] = c[1][1];
             __syncthreads();
             dg_tile_gemm(32,
-                         [&](int i, int k) { return Xf(32 * bi + i, 32 * bi + k); },
+                         [&](int i, int k) { return T2[i * 33 + k]; },
                          [&](int k, int j) { return T[k * 33 + j]; }, c);
             __syncthreads();                       // every thread is done with T and with the X blocks it read
             S[(32 * bj + tj) * DG_LD + 32 * bi + ti] = -c[0][0];
@@ -503,14 +553,17 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
             S[(32 * bj + tj + 1) * DG_LD + 32 * bi + ti + 1] = -c[1][1];
             __syncthreads();
         }
-    for (int e = tid; e < n * n; e += 256) {
-        const int i = e / n, j = e - i * n;
-        A[(long)i * lda + j] = (j <= i) ? S[i * DG_LD + j] : 0.0;
+    DG_STAMP(14);
+    for (int e = tid; e < 128 * 128; e += 256) {
+        const int i = e >> 7, j = e & 127;
+        if (i < n && j < n) A[(long)i * lda + j] = (j <= i) ? S[i * DG_LD + j] : 0.0;
     }
     for (int e = tid; e < 128 * 128; e += 256) {
         const int i = e >> 7, j = e & 127;
         Linv[e] = (i < n && j <= i) ? (i == j ? dinv[i] : S[j * DG_LD + i]) : 0.0;
     }
+    DG_STAMP(15);
+    DG_STAMP_PRINT();
 }
 
 // helpers --------------------------------------------------------------------------------------

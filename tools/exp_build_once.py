@@ -1,11 +1,15 @@
-"""Dev: one matrix build (for rocprofv3 --pmc / --kernel-trace).  python tools/exp_build_once.py N"""
-import sys
+"""Dev: matrix builds for rocprofv3 (--pmc / --kernel-trace): a warm-up build, then `reps` timed ones.  python tools/exp_build_once.py N [reps]"""
+import sys, time
 sys.path.insert(0, ".")
 from magi_v2_amd import host
 from magi_v2_amd.engine import MagiEngine
-N = int(sys.argv[1]); D = 4
+N = int(sys.argv[1]); reps = int(sys.argv[2]) if len(sys.argv) > 2 else 1; D = 4
 I, X_obs, truth, th = host.synthetic_seir(N, seed=0)
 hp = host.hparams_initial(host.linear_interpolate(X_obs))
 eng = MagiEngine(0)
 eng.build_matrices(I, hp["phi1s"], hp["phi2s"], 2.01, want_host=False)
+for r in range(reps - 1):
+    t = time.perf_counter()
+    eng.build_matrices(I, hp["phi1s"], hp["phi2s"], 2.01, want_host=False)
+    print("build %d: %.2f ms" % (r, (time.perf_counter() - t) * 1e3))
 eng.close()
