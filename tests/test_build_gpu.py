@@ -107,6 +107,20 @@ def test_build_multi_block_inverse_property(eng, N):
         assert np.abs(K_inv[d] @ K_ref - np.eye(N)).max() < 200 * cond * EPS * condK ** 0.5
 
 
+def test_concurrent_and_serial_component_builds_are_identical(eng, monkeypatch):
+    """The D components are built on D streams / work spaces by default, one after the other on one work space with
+    MAGI_BUILD_SERIAL=1 (also the path taken when HBM is short): same kernels, same operands, so the matrices must
+    be bit-identical -- any difference would be a missing dependency between streams."""
+    N = 300
+    I = np.arange(N) * 0.025
+    phi1, phi2 = np.array([0.03, 0.2, 1.1, 0.5]), np.array([0.3, 0.15, 0.4, 0.22])
+    conc = eng.build_matrices(I, phi1, phi2, 2.01)
+    monkeypatch.setenv("MAGI_BUILD_SERIAL", "1")
+    ser = eng.build_matrices(I, phi1, phi2, 2.01)
+    for a, b in zip(conc, ser):
+        assert np.array_equal(a, b)
+
+
 def test_built_matrices_feed_logpost_and_band(eng):
     """End to end on the device-resident matrices: build (band 80 at N=161 -> masked dense) and
     evaluate the log posterior; compare with the oracle on the ORACLE's matrices.  Agreement is

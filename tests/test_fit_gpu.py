@@ -18,6 +18,27 @@ def data():
     return g["seir3_I"][:, 0], g["seir3_X_interp"], g
 
 
+def test_device_resident_loop_equals_host_loop(data, monkeypatch):
+    """The fit replays one captured graph per Adam step with the scalar tail (likelihood, priors, Adam) in a one-thread
+    kernel; MAGI_FIT_HOST_LOOP=1 runs the same kernels with that tail on the host.  Same arithmetic up to libm."""
+    from magi_v2_amd.engine import MagiEngine
+    I, X, g = data
+    I, X = I[:161], X[:161]
+    pri = [orc.fourier_phi2_prior(X[:, d]) for d in range(3)]
+    init = orc.hparams_initial(X)
+    outs = []
+    for host_loop in (False, True):
+        if host_loop:
+            monkeypatch.setenv("MAGI_FIT_HOST_LOOP", "1")
+        eng = MagiEngine(0)
+        outs.append(eng.fit_hparams(I, X, X.mean(axis=0), [p[0] for p in pri], [p[1] for p in pri], init["sigma_sqs"],
+                                    init["phi1s"], init["phi2s"], init["sigma_sqs"], num_iters=60, want_trace=True))
+        eng.close()
+    for k in ("phi1s", "phi2s", "sigma_sqs"):
+        np.testing.assert_allclose(outs[0][k], outs[1][k], rtol=1e-9)
+    np.testing.assert_allclose(outs[0]["loss"], outs[1]["loss"], rtol=1e-11)
+
+
 def test_single_adam_step_equals_oracle(data):
     """One iteration isolates the device marginal-likelihood gradient: after a single Adam step every variable
     moves by lr in the direction -sign(grad), so compare a 1-step and a 25-step trajectory with the oracle."""
