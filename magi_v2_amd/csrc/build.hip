@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
 #pragma unroll
                 for (int j = k + 1; j < 32; ++j) {
                     const double ljk = readlane_f64(d[k], j);
-                    if (r >= j) d[j] = fma(-d[k], ljk, d[j]);
+                    d[j] = fma(-d[k], ljk, d[j]);          // (rows r < j compute garbage in the upper triangle, which nothing reads: no predicate)
                 }
             }
             if (fail >= 0 && lane == 0) bad = fail;
