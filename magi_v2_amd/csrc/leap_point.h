@@ -134,7 +134,13 @@ __device__ __forceinline__ void point_block(const DevProblem& pb, const DevChain
 #pragma unroll
                 for (int k = 0; k < 8; ++k) sum += u[k];
             }
-            for (; sl <= s1; ++sl) sum += src[(size_t)sl * pb.Np];
+            if (sl <= s1) {        // ragged tail (1..7 slots): one batch from clamped addresses -- a `sum += src[..]` loop waits per slot
+                double u[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) u[k] = src[(size_t)min(sl + k, s1) * pb.Np];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sum += (sl + k <= s1) ? u[k] : 0.0;
+            }
         }
         res[(pt * PT_DSLOT + d) * 4 + v] = sum;
     }

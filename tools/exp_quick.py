@@ -6,7 +6,7 @@ from magi_v2_amd import host
 from magi_v2_amd.engine import MagiEngine
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 nch = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-band = int(sys.argv[3]) if len(sys.argv) > 3 else None
+band = (int(sys.argv[3]) if len(sys.argv) > 3 else 0) or None          # 0 = dense
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 I, X_obs, truth, th = host.synthetic_seir(N, seed=0)
 Xi = host.linear_interpolate(X_obs); hp = host.hparams_initial(Xi)
