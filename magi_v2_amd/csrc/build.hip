@@ -1013,11 +1013,12 @@ int magi_fused_operators(magi_handle* h, int N, int D, double* dCs_inout_H, cons
     g.batchA = nn; g.batchB = nn; g.batchC = nn;
     int rc = launch_gemm(h, h->stream, g, D, BC_FUSED);
     if (rc) return rc;
-    GemmArgs t{};     // H = M^T E + Cs
+    GemmArgs t{};     // H = M^T E + Cs   (block rows at or below the block diagonal)
     t.A = dM; t.sAm = 1; t.sAk = N;
     t.B = dE; t.sBn = 1; t.sBk = N;
     t.C = dCs_inout_H; t.ldc = N; t.M = N; t.N = N; t.K = N; t.alpha = 1.0; t.beta = 1.0;
     t.batchA = nn; t.batchB = nn; t.batchC = nn;
+    t.lower_only = 1;     // H is symmetric and the tile packer reads its lower block triangle only (pack.hip)
     return launch_gemm(h, h->stream, t, D, BC_FUSED);
 }
 
