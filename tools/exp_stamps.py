@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, ".")
 from magi_v2_amd import host
 from magi_v2_amd.engine import MagiEngine
-N = 1024
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 I, X_obs, truth, th = host.synthetic_seir(N, seed=0)
 Xi = host.linear_interpolate(X_obs); hp = host.hparams_initial(Xi)
 N_ds, beta, idx, y = host.observation_bookkeeping(X_obs, X_obs)
