@@ -34,17 +34,19 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=int, default=1024, help="N grid points")
-    ap.add_argument("--chains-per-gpu", type=int, default=1)
+    ap.add_argument("--chains-per-gpu", type=int, default=1,
+                    help="chains sampled on every GPU.  1 = BASELINE config 2 (the N=1 headline); 8 = config 3 "
+                         "(64 independent chains over 8 GPUs): python -m torch.distributed.run ... bench.py --gpus 8 --chains-per-gpu 8")
     ap.add_argument("--burnin", type=int, default=40, help="untimed adaptation steps before warmup")
     ap.add_argument("--band", type=int, default=-1, help="bandsize (-1 = dense)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2, help="oracle NUTS transitions for the CPU baseline")
     ap.add_argument("--seed", type=int, default=20250103)
-    ap.add_argument("--distinct-chains", action="store_true",
-                    help="give every rank its own Philox chain ids (statistically independent chains).  Default: every rank "
-                         "runs the chain ids of the 1-GPU run, so per-GPU work is identical for every N (weak scaling); NUTS "
-                         "trees of independent chains differ by up to 2x in leapfrogs per sample, which a max-over-ranks "
-                         "timer would report as a scaling loss (DESIGN.md section 5)")
+    ap.add_argument("--replicate-chains", action="store_true",
+                    help="DIAGNOSTIC ONLY: every rank samples the chain ids of rank 0 (identical per-GPU work, bit-identical "
+                         "chains).  The default gives every chain of the job its own Philox stream -- independent chains, as "
+                         "BASELINE config 3 asks -- so the max-over-ranks time includes the NUTS tree-size spread between chains")
+    ap.add_argument("--cpu-threads", type=str, default="1,8,32,all", help="thread counts of the torch-CPU baseline leg")
     return ap.parse_args()
 
 
@@ -100,7 +102,7 @@ def main():
     rep = lambda v: np.repeat(np.asarray(v)[None], cpg, axis=0)
     from magi_v2_amd.shard import chain_ids_for_rank
     unit_ids = chain_ids_for_rank(rank, world, cpg * world)              # which (dataset, chain) units this rank owns
-    chain_ids = unit_ids if a.distinct_chains else list(range(cpg))      # the Philox streams they are sampled with
+    chain_ids = list(range(cpg)) if a.replicate_chains else unit_ids     # the Philox streams they are sampled with
     eng.sampler_init(cfg, rep(Xhat), rep(sig_pre0), rep(th_pre0), seed=a.seed, chain_ids=chain_ids)
     eng.sampler_run(a.burnin)
     if a.warmup > 0:
@@ -160,21 +162,39 @@ def main():
     hmc = {"samples_per_s": round(cpg * a.steps / hmc_s, 2), "leapfrogs_per_s": round(hlf / hmc_s, 1), "L": 32,
            "accept_rate": round(float(hd.is_accepted[:, 100:].mean()), 3), "step_size": float(hd.step_size[0, -1]), "scope": "rank 0"}
 
-    # ---- roofline of the dominant kernel (phase-1 mat-vec), HIP events on the engine's stream -----------
+    # ---- roofline of the dominant kernel (k_stream), HIP events on the engine's stream -----------------
     grad_ms, phase_ms = eng.time_gradient(cpg, 300)
     phase_bytes = eng.gradient_bytes(cpg)
-    # dominant kernel of the sampler = the streaming kernel k_stream (index 4).  "achieved" uses the ALGORITHMIC
-    # bytes of one gradient (3 D N W 8 + C 10 N D 8).  The kernel itself streams fewer: the symmetric
-    # operators FH and FK are stored as their lower block triangle and FE serves both FE xc and FE^T f, i.e. about
-    # 2 N^2 D values instead of 3 (bytes_per_launch); the fraction can therefore exceed streamed_GBps / peak.
+    # "achieved" / "frac" are SURVEY 8d's contract: the ALGORITHMIC bytes of one gradient (3 D N W 8 + C 10 N D 8) over the
+    # kernel's launch time.  The kernel itself streams fewer bytes: the symmetric operators FH and FK are stored as their
+    # lower block triangle and FE serves both FE xc and FE^T f -- about 2 N^2 D values instead of 3 (bytes_per_launch).
+    # frac_bytes_moved prices those bytes against the same peak; ceiling_GBps is a load-only pass over the same blocks with
+    # the same access pattern, timed here; slot_frac is the per-leapfrog view (algorithmic bytes over the whole slot
+    # [k_stream, k_point] as the sampler ran it in the timed region).
     W = N if band is None or 6 * band + 1 >= N else 2 * band + 1
     algorithmic = 3.0 * D * N * W * 8.0 + cpg * 10.0 * N * D * 8.0
-    achieved = algorithmic / (phase_ms[4] * 1e-3) / 1e9
+    t_stream = phase_ms[4] * 1e-3
+    achieved = algorithmic / t_stream / 1e9
+    slot_s = elapsed / (lf_total / n_chains)                                 # seconds per leapfrog slot (one leapfrog of every chain on the GPU)
+    n_tasks = phase_bytes[4] / (128 * 128 * 8.0 + 2.0 * cpg * 128 * 8.0)     # packed 128 x 128 blocks (magi_gradient_bytes)
+    tiles_bytes = n_tasks * 128 * 128 * 8.0
     roofline = {"bound": "hbm", "kernel": "k_stream (single-phase block mat-vecs FH xc, FE xc, FE^T f, FK f over packed 128x128 blocks)",
                 "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
                 "traffic": None, "algorithmic_bytes_per_launch": algorithmic, "bytes_per_launch": phase_bytes[4],
-                "streamed_GBps": round(phase_bytes[4] / (phase_ms[4] * 1e-3) / 1e9, 1), "us_per_launch": round(phase_ms[4] * 1e3, 3),
-                "kernels_us": dict(zip(["phase1", "phase2", "phase3", "reduce", "stream", "leap_reduce", "point"], [round(x * 1e3, 3) for x in phase_ms[:7]])),
+                "streamed_GBps": round(phase_bytes[4] / t_stream / 1e9, 1),
+                "frac_bytes_moved": round(phase_bytes[4] / t_stream / 1e9 / 8000.0, 4),
+                "ceiling_GBps": round(tiles_bytes / (phase_ms[7] * 1e-3) / 1e9, 1),
+                "ceiling_note": "load-only kernel over the same packed blocks, same 16-B-per-lane pattern, timed in this run; "
+                                "frac_of_ceiling = streamed_GBps / ceiling_GBps",
+                "frac_of_ceiling": round((phase_bytes[4] / t_stream) / (tiles_bytes / (phase_ms[7] * 1e-3)), 4),
+                "slot_frac": round(algorithmic / slot_s / 1e9 / 8000.0, 4),
+                "slot_frac_bytes_moved": round((phase_bytes[4] + phase_bytes[6]) / slot_s / 1e9 / 8000.0, 4),
+                "working_set": f"{phase_bytes[4] / 1e6:.1f} MB of operator blocks per launch: " +
+                               ("resident in the 256 MiB Infinity Cache between launches (not in the 8 x 4 MiB L2s), so the HBM peak is "
+                                "the contract's yardstick, not the physical source of the bytes" if phase_bytes[4] < 200e6 else
+                                "larger than the 256 MiB Infinity Cache: streamed from HBM"),
+                "us_per_launch": round(phase_ms[4] * 1e3, 3),
+                "kernels_us": dict(zip(["phase1", "phase2", "phase3", "reduce", "stream", "leap_reduce", "point", "read_only"], [round(x * 1e3, 3) for x in phase_ms[:8]])),
                 "three_phase_gradient_eval_us": round(grad_ms * 1e3, 3)}
 
     # measured memory-side traffic of the same kernel on the same workload, from the committed PMC passes
@@ -182,50 +202,63 @@ def main():
     try:
         import csv
         if N == 1024 and cpg == 1 and (band is None or 6 * band + 1 >= N):
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_bench_pmc_traffic.csv")) as fh:
+            prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            name = next(f for f in ("r02_bench_pmc_traffic.csv", "r01_bench_pmc_traffic.csv") if os.path.exists(os.path.join(prof, f)))
+            with open(os.path.join(prof, name)) as fh:
                 tr = sum(float(r["bytes_per_launch_corrected"]) for r in csv.DictReader(fh) if "k_stream<1, 1>" in r["Kernel_Name"])
             if tr > 0:
                 roofline["traffic"] = tr
-                roofline["traffic_source"] = "profiles/r01_bench_pmc_traffic.csv (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
-    except (OSError, KeyError, ValueError):
+                roofline["traffic_source"] = f"profiles/{name} (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+    except (OSError, KeyError, ValueError, StopIteration):
         pass
 
-    # ---- CPU baseline: the numpy oracle continues the SAME chain from the GPU's current state -----------
+    # ---- CPU baseline: torch-CPU fp64 restatement of magi_v2.py:308-348 (bmm + autograd, what XLA-CPU executes for
+    #      the reference), timed at several thread counts on this host; samples/s = gradient evaluations/s over the leapfrogs
+    #      per sample the GPU chain needed in the timed region.  Second leg: the numpy oracle continuing the SAME chain. ----
     cpu = None
     if world == 1 and not a.no_cpu_baseline:
         from oracle import magi_oracle as orc
+        from oracle import torch_cpu
         import threadpoolctl
         C_inv, m, K_inv = mats
         pr = orc.Problem(I=I, mu=Xi.mean(axis=0), C_inv=orc.band_part(C_inv, band), m=orc.band_part(m, band),
                          K_inv=orc.band_part(K_inv, band), N_ds=N_ds.astype(np.float64), obs_idx=idx, y=y, beta=float(beta),
                          LB=LB, drift="seir4", P=P)
         Xc, spc, tpc, ss, bc = state
+        ncpu = os.cpu_count() or 1
+        threads = sorted({min(ncpu, ncpu if t == "all" else int(t)) for t in a.cpu_threads.split(",")})
+        lf_per_sample = lf_total / (n_chains * a.steps)
+        rates = torch_cpu.time_gradients(pr, Xc[0], spc[0], tpc[0], threads, min_evals=200, max_seconds=6.0)
+        best_t = max(rates, key=rates.get)
+        try:
+            with open("/proc/cpuinfo") as fh:
+                cpu_model = next(l.split(":", 1)[1].strip() for l in fh if l.startswith("model name"))
+        except (OSError, StopIteration):
+            cpu_model = "unknown"
+        cpu = {"value": round(rates[best_t] / lf_per_sample, 5), "unit": "samples/s", "cores": best_t, "kind": "port",
+               "sample": f">= 200 value+gradient evaluations (or 6 s) per thread count of oracle/torch_cpu.py -- torch-CPU fp64 bmm + autograd "
+                         f"restatement of magi_v2.py:308-348 -- at the GPU chain's state; converted with the {lf_per_sample:.1f} leapfrogs per "
+                         "sample of the timed GPU region",
+               "gradient_evals_per_s": {str(t): round(r, 2) for t, r in rates.items()}, "leapfrogs_per_s": round(rates[best_t], 2),
+               "host_cpus": ncpu, "cpu_model": cpu_model}
+        # second leg: the numpy oracle (restated TFP NUTS) continues the same chain for a few transitions
         q = orc.pack(Xc[0], spc[0], tpc[0])
         fn_L = orc.make_fn_L(pr)
         L, gL = fn_L(q)
         k = total
         tc0 = time.perf_counter()
         n_lf = 0
-        for s in range(a.cpu_steps):
-            temp = orc.temperature(k + s)
-            res = orc.nuts_one_step(q, temp * L, temp * gL, float(ss[0]), temp, fn_L, k + s, chain_ids[0], a.seed)
+        for s_ in range(a.cpu_steps):
+            temp = orc.temperature(k + s_)
+            res = orc.nuts_one_step(q, temp * L, temp * gL, float(ss[0]), temp, fn_L, k + s_, chain_ids[0], a.seed)
             n_lf += res.leapfrogs
             if res.is_accepted:
                 q, L, gL = res.q, res.L, res.gL
         cpu_s = time.perf_counter() - tc0
-        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] + [1])
-        cpu = {"value": round(a.cpu_steps / cpu_s, 5), "unit": "samples/s", "cores": threads, "kind": "port",
-               "sample": f"{a.cpu_steps} NUTS transitions ({n_lf} leapfrogs) of the same chain continued from the GPU state by "
-                         "oracle/magi_oracle.py (numpy + OpenBLAS restatement of magi_v2.py:308-348 and TFP NUTS)",
-               "leapfrogs_per_s": round(n_lf / cpu_s, 2), "host_cpus": os.cpu_count()}
-        # the same gradient on ONE host thread (SURVEY 8d asks for both): 40 evaluations, scaled by the leapfrogs per sample above
-        with threadpoolctl.threadpool_limits(limits=1):
-            fn_L(q)
-            t1 = time.perf_counter()
-            for _ in range(40):
-                fn_L(q)
-            g1 = 40.0 / (time.perf_counter() - t1)
-        cpu["single_thread"] = {"leapfrogs_per_s": round(g1, 2), "samples_per_s": round(g1 / (n_lf / a.cpu_steps), 5)}
+        nthreads = max([p_.get("num_threads", 1) for p_ in threadpoolctl.threadpool_info()] + [1])
+        cpu["numpy_nuts_leg"] = {"samples_per_s": round(a.cpu_steps / cpu_s, 5), "leapfrogs_per_s": round(n_lf / cpu_s, 2), "threads": nthreads,
+                                 "sample": f"{a.cpu_steps} NUTS transitions ({n_lf} leapfrogs) of the same chain continued from the GPU state by "
+                                           "oracle/magi_oracle.py (numpy + OpenBLAS; streams six matrices per gradient, batched matmul does not thread)"}
 
     out = {
         "metric": "HMC samples/sec (whole node) on SEIR, N grid pts x D comps",
@@ -236,15 +269,18 @@ def main():
                                f"NUTS(max depth 10)+dual averaging+log annealing, {cpg} chain(s)/GPU",
                    "grid": N, "components": D, "thetas": P, "chains_total": n_chains, "bandsize": band,
                    "burnin_untimed": a.burnin, "parallelism": f"chains x{world}",
-                   "chain_streams": "distinct per rank" if a.distinct_chains or world == 1 else
-                                    "every rank samples the 1-GPU run's chain ids (identical per-GPU work)"},
+                   "stale_cache": 0, "stale_cache_note": "the reference's annealed kernel reuses the previous step's cached target (computed at the "
+                                   "previous temperature); on this synthetic grid that offset rejects every proposal, so the bench recomputes at "
+                                   "the current temperature -- same arithmetic per leapfrog (DESIGN.md 4.2)",
+                   "chain_streams": "DIAGNOSTIC: every rank replicates rank 0's chain ids" if a.replicate_chains else
+                                    "independent: Philox stream = global chain id (rank * chains_per_gpu + local index)"},
         "roofline": roofline, "cpu_baseline": cpu,
         "leapfrogs_per_s": round(lf_total / elapsed, 1), "us_per_leapfrog_slot": round(elapsed / (lf_total / n_chains) * 1e6, 2),
         "mean_tree_depth": round(float(post.mean()), 2), "device_ms": round(dev_ms, 2), "build_ms": round(build_ms, 1),
         "gather_ms": round(gather_ms, 3), "hmc_L32": hmc, "theta_mean": [round(float(x), 4) for x in np.log1p(np.exp(th_all)).reshape(-1, P).mean(axis=0)],
     }
     if cpu:
-        out["speedup_vs_cpu_port"] = round(value / cpu["value"], 1)
+        out["speedup_vs_cpu_port"] = round(value / cpu["value"], 1)          # against the BEST thread count of the torch-CPU leg
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -190,8 +190,9 @@ int magi_sample(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains,
 /* Launch one gradient evaluation (the 3 mat-vec phases + reduce) `reps` times on the handle's
  * stream, bracketed by HIP events on that stream; phase_ms[8] receives the average device
  * time per launch of phase 1, 2, 3, the reduce kernel, the sampler's streaming kernel (single-phase
- * block mat-vecs, k_stream), its reduce (k_leap_finalize) and its point kernel (k_point; [7] is
- * unused), measured in separate event-bracketed loops.  Uses the states currently on the
+ * block mat-vecs, k_stream), its reduce (k_leap_finalize), its point kernel (k_point) and, in [7], a
+ * load-only pass over the same packed operator blocks with the same access pattern (the ceiling the
+ * memory system offers k_stream for this layout and working set), measured in separate event-bracketed loops.  Uses the states currently on the
  * device (n_chains as last set). */
 int magi_time_gradient(magi_handle* h, int n_chains, int reps, double* total_ms_per_eval, double* phase_ms);
 

@@ -205,16 +205,15 @@ int magi_set_matrices(magi_handle* h, int N, int D, int bandsize, const double* 
     if (N < 2 || D < 1 || D > MAGI_MAX_D) return magi_fail(h, MAGI_E_BADARG, "need N >= 2 and 1 <= D <= " + std::to_string(MAGI_MAX_D));
     (void)hipSetDevice(h->device);
     const size_t bytes = (size_t)D * N * N * sizeof(double);
-    double *dC = nullptr, *dm = nullptr, *dK = nullptr;
-    MAGI_HIP_CHECK(h, hipMalloc(&dC, bytes));
-    MAGI_HIP_CHECK(h, hipMalloc(&dm, bytes));
-    MAGI_HIP_CHECK(h, hipMalloc(&dK, bytes));
-    MAGI_HIP_CHECK(h, hipMemcpy(dC, C_inv, bytes, hipMemcpyHostToDevice));
-    MAGI_HIP_CHECK(h, hipMemcpy(dm, m, bytes, hipMemcpyHostToDevice));
-    MAGI_HIP_CHECK(h, hipMemcpy(dK, K_inv, bytes, hipMemcpyHostToDevice));
-    int rc = magi_pack_matrices(h, N, D, bandsize, dC, dm, dK);
+    struct Tmp { double* p = nullptr; ~Tmp() { free_dev(p); } } dC, dm, dK;      // freed on every return path
+    MAGI_HIP_CHECK(h, hipMalloc(&dC.p, bytes));
+    MAGI_HIP_CHECK(h, hipMalloc(&dm.p, bytes));
+    MAGI_HIP_CHECK(h, hipMalloc(&dK.p, bytes));
+    MAGI_HIP_CHECK(h, hipMemcpy(dC.p, C_inv, bytes, hipMemcpyHostToDevice));
+    MAGI_HIP_CHECK(h, hipMemcpy(dm.p, m, bytes, hipMemcpyHostToDevice));
+    MAGI_HIP_CHECK(h, hipMemcpy(dK.p, K_inv, bytes, hipMemcpyHostToDevice));
+    int rc = magi_pack_matrices(h, N, D, bandsize, dC.p, dm.p, dK.p);
     (void)hipStreamSynchronize(h->stream);
-    free_dev(dC); free_dev(dm); free_dev(dK);
     return rc;
 }
 
@@ -404,6 +403,12 @@ int magi_sampler_init(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains,
         MAGI_HIP_CHECK(h, hipMalloc(&d.d_flags, need_d * sizeof(int)));
         h->diag_cap = need_d;
     }
+    {   // steps not taken yet read as NaN / -1, not as whatever the allocation held
+        DevChains& d = h->ch;
+        MAGI_HIP_CHECK(h, hipMemsetAsync(d.samples, 0xFF, need_s * sizeof(double), h->stream));
+        for (double* p : {d.d_step_size, d.d_lar, d.d_target, d.d_energy, d.d_beta}) MAGI_HIP_CHECK(h, hipMemsetAsync(p, 0xFF, need_d * sizeof(double), h->stream));
+        for (int* p : {d.d_leapfrogs, d.d_depth, d.d_flags}) MAGI_HIP_CHECK(h, hipMemsetAsync(p, 0xFF, need_d * sizeof(int), h->stream));
+    }
     drop_graph(h);   // kernel arguments (cfg, buffers) are baked into the captured graph
 
     if ((rc = upload_states(h, n_chains, X0, sig_pre0, th_pre0))) return rc;
@@ -465,8 +470,20 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
     const int depth = 2;
     long long issued = 0, retired = 0;
     bool done = false;
-    const long long max_graphs = 1ll << 40;
+    // every slot advances every unfinished chain by a leaf or a set-up step, so a transition takes at most 2^max_depth - 1 leaves
+    // + one set-up slot per doubling + start / end: a pump that outlives that budget means a corrupted control block
+    const long long per_transition = (h->cfg.mode == MAGI_MODE_HMC ? (long long)h->cfg.hmc_L : (1ll << (h->cfg.max_depth + 1))) + h->cfg.max_depth + 4;
+    const long long max_graphs = ((long long)(g.stop_k - kmin) * per_transition + 8) / kGraphSlots + 4;
     while (!done) {
+        if (issued >= max_graphs && issued == retired) {
+            (void)hipStreamSynchronize(h->stream);
+            (void)hipMemcpy(ctl.data(), h->ch.ctl, sizeof(ChainCtl) * h->n_chains, hipMemcpyDeviceToHost);
+            std::string where;
+            for (int i = 0; i < h->n_chains; ++i)
+                if (ctl[i].phase != PH_IDLE || ctl[i].k < g.stop_k) { where = " (chain " + std::to_string(i) + ": k=" + std::to_string(ctl[i].k) + ", phase=" + std::to_string(ctl[i].phase) + ", depth=" + std::to_string(ctl[i].depth) + ")"; break; }
+            h->sampler_ready = false;
+            return magi_fail(h, MAGI_E_STATE, "sampler did not finish within its slot budget" + where);
+        }
         while (issued - retired < depth && issued < max_graphs) {
             const int slot = (int)(issued % 4);
             if (use_graph) {
@@ -481,6 +498,7 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
             MAGI_HIP_CHECK(h, hipEventRecord(h->ev[slot], h->stream));
             ++issued;
         }
+        if (issued == retired) continue;
         const int slot = (int)(retired % 4);
         MAGI_HIP_CHECK(h, hipEventSynchronize(h->ev[slot]));
         if (h->h_gctl[slot].all_done) done = true;
@@ -650,14 +668,15 @@ int magi_time_gradient(magi_handle* h, int n_chains, int reps, double* total_ms_
     MAGI_HIP_CHECK(h, hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
     if (total_ms_per_eval) *total_ms_per_eval = ms / reps;
     if (phase_ms) {
-        for (int ph = 1; ph <= 7; ++ph) {
+        for (int ph = 1; ph <= 8; ++ph) {
             MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t0, h->stream));
             for (int i = 0; i < reps; ++i) {
                 if (ph <= 3) rc = magi_launch_phase(h, ph, n_chains, h->stream);
                 else if (ph == 4) rc = magi_launch_finalize(h, n_chains, h->d_fin, h->stream);
                 else if (ph == 5) rc = magi_launch_stream(h, n_chains, 0, false, h->stream);
                 else if (ph == 6) rc = magi_launch_leap_finalize(h, n_chains, h->d_fin, h->stream);
-                else rc = magi_launch_point(h, n_chains, 0, h->stream);
+                else if (ph == 7) rc = magi_launch_point(h, n_chains, 0, h->stream);
+                else rc = magi_launch_read_tiles(h, h->stream);
                 if (rc) return rc;
             }
             MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t1, h->stream));

@@ -275,6 +275,16 @@ __global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains c
     point_block<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, res, redk, s_mu);
 }
 
+// load-only twin of k_stream's tile stream (bench.py's ceiling leg): every workgroup reads its 128 KB block with the same
+// 16-B-per-lane pattern and does nothing else -- what the memory system delivers for this layout and working set
+__global__ __launch_bounds__(256) void k_read_tiles(const double2* __restrict__ p, double* out) {
+    const double2* q = p + (size_t)blockIdx.x * (MAGI_TB * MAGI_TB / 2) + threadIdx.x;
+    double a = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAGI_TB * MAGI_TB / 2 / 256; ++r) { const double2 v = q[r * 256]; a += v.x + v.y; }
+    if (a == 12345.678) out[0] = a;
+}
+
 // validation plan (magi_logpost_grad_fused / timing): slot 0 evaluates buffer 0 as is, no leapfrog
 __global__ void k_plan_eval(DevChains ch) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -343,6 +353,13 @@ int magi_launch_point(magi_handle* h, int n_chains, int parity, hipStream_t s) {
 #undef MAGI_CALL
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("point launch: ") + hipGetErrorString(e));
+    return MAGI_OK;
+}
+
+int magi_launch_read_tiles(magi_handle* h, hipStream_t s) {
+    hipLaunchKernelGGL(k_read_tiles, dim3(h->pb.n_tasks), dim3(256), 0, s, reinterpret_cast<const double2*>(h->pb.tiles), h->d_fin);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("read_tiles launch: ") + hipGetErrorString(e));
     return MAGI_OK;
 }
 

@@ -763,6 +763,7 @@ int magi_build_profile_get(double* flops, double* ms, long* calls);           //
 int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const double* X, const double* mu, const double* mu_phi2,
                             const double* sd_phi2, const double* sig_loc, double nu, int iters, double lr, double jitter,
                             double* phi1, double* phi2, double* sig2, double* loss_trace);
+int magi_launch_read_tiles(magi_handle* h, hipStream_t s);                     // load-only pass over the packed operator blocks
 int magi_launch_plan_eval(magi_handle* h, int n_chains, hipStream_t s);        // plan: evaluate buffer 0, no leapfrog                                       // workgroups along the grid axis
 // build.hip: E = Ks M, H = Cs + M^T E for D dense [N][N] components (H overwrites Cs)
 int magi_fused_operators(magi_handle* h, int N, int D, double* dCs_inout_H, const double* dM, const double* dKs, double* dE);

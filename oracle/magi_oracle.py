@@ -259,6 +259,85 @@ def build_all(I: np.ndarray, phi1s, phi2s, v: float = 2.01, bandsize: Optional[i
 
 
 # --------------------------------------------------------------------------------------
+def adam_minimise(value_and_grad, x0, iters, lr=0.01, b1=0.9, b2=0.999, eps=1e-7):
+    """tf_keras.optimizers.Adam(learning_rate=lr) at its defaults (beta_1 .9, beta_2 .999, epsilon 1e-7, no amsgrad), the
+    optimiser of magi_v2.py:161, 230, 654:  m, v moments;  x -= lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps).
+    ``x0`` / the gradients may be a single array or a list of arrays (Adam is element-wise).  Returns (x, losses)."""
+    xs = [np.array(a, dtype=np.float64) for a in (x0 if isinstance(x0, (list, tuple)) else [x0])]
+    ms, vs = [np.zeros_like(a) for a in xs], [np.zeros_like(a) for a in xs]
+    losses = []
+    for t in range(1, iters + 1):
+        loss, grads = value_and_grad(*xs)
+        grads = grads if isinstance(grads, (list, tuple)) else [grads]
+        losses.append(loss)
+        alpha = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+        for k, g in enumerate(grads):
+            ms[k] = b1 * ms[k] + (1.0 - b1) * g
+            vs[k] = b2 * vs[k] + (1.0 - b2) * g * g
+            xs[k] = xs[k] - alpha * ms[k] / (np.sqrt(vs[k]) + eps)
+    return (xs if isinstance(x0, (list, tuple)) else xs[0]), np.array(losses)
+
+
+def theta_init_objective(thetas, Xhat_init, mu_ds, m_ds, K_d_invs, drift):
+    """``theta_objective`` of magi_v2.py:148-158 and its gradient with respect to theta.
+
+    Operation for operation, INCLUDING the reference's ``tf.reshape`` of the [N, D] drift values to [D, N, 1]
+    (magi_v2.py:155-156; the log posterior transposes instead, :335), which re-interprets the row-major buffer: entry
+    (d, n) of the reshaped array is element d*N + n of the flattened [N, D] array.  ``m_ds`` / ``K_d_invs`` are the
+    matrices BEFORE the band approximation (the initialiser runs at :133-179, the band is applied at :271-274) and
+    ``Xhat_init`` is the interpolated grid before smoothing (:112-113, smoothing at :277).
+    The reference differentiates with tf.GradientTape (:164-166); the gradient here is the same derivative written out:
+    d/dtheta_p = sum_d reshape(df/dtheta_p)_d^T (K_d^-1 + K_d^-T) toNorm_d."""
+    N, D = Xhat_init.shape
+    X_cent = (Xhat_init - mu_ds).reshape(N, 1, D)                                   # :139-141
+    m_prod = m_ds @ np.transpose(X_cent, (2, 0, 1))                                 # :142   [D, N, 1]
+    f, _, T = DRIFTS[drift][0](Xhat_init, thetas)                                   # [N, D], -, [N, D, P]
+    f_vals = np.reshape(f, (D, N, 1))                                               # :155-156 (reshape, not transpose)
+    toNorm = f_vals - m_prod                                                        # :157
+    Kt = K_d_invs @ toNorm
+    val = float(np.sum(np.transpose(toNorm, (0, 2, 1)) @ Kt))                       # :158
+    g = (Kt + np.transpose(K_d_invs, (0, 2, 1)) @ toNorm)[:, :, 0]                  # [D, N]
+    P = T.shape[2]
+    grad = np.array([np.sum(np.reshape(T[:, :, p], (D, N)) * g) for p in range(P)])
+    return val, grad
+
+
+def fit_thetas_init(Xhat_init, mu_ds, m_ds, K_d_invs, drift, P, num_iters=10000, lr=0.01):
+    """magi_v2.py:133-179: Adam(lr=.01) x 10 000 on ``theta_objective`` from theta = 1."""
+    fn = lambda th: theta_init_objective(th, Xhat_init, mu_ds, m_ds, K_d_invs, drift)
+    th, losses = adam_minimise(fn, np.ones(P), num_iters, lr)
+    return th, losses
+
+
+def gradient_matching_loss_and_grads(I, X_obs_smoothed, X_unobs, thetas, proper_order, unobserved_components, drift):
+    """``unobserved_objective`` of magi_v2.py:199-216 with its gradients with respect to (X_unobs, thetas) written out
+    (the reference uses tf.GradientTape, :233-235)."""
+    X_full = np.concatenate([X_obs_smoothed, X_unobs], axis=1)[:, proper_order]
+    f, J, T = DRIFTS[drift][0](X_full, thetas)
+    h2 = 2 * (I[1, 0] - I[0, 0])
+    r = f[1:-1] - (X_full[2:, :] - X_full[:-2, :]) / h2                             # [N-2, D]
+    gX = np.zeros_like(X_full)
+    gX[1:-1] += 2.0 * np.einsum("nd,nde->ne", r, J[1:-1])
+    gX[2:] -= 2.0 * r / h2
+    gX[:-2] += 2.0 * r / h2
+    gth = 2.0 * np.einsum("nd,ndp->p", r, T[1:-1])
+    return float(np.sum(r ** 2)), gX[:, unobserved_components], gth
+
+
+def fit_unobserved(I, X_interp_obs, X_obs_smoothed, proper_order, unobserved_components, drift, P, seed, num_iters=10000, lr=0.01):
+    """magi_v2.py:182-249: joint Adam on (X_unobs, theta) from X_unobs ~ N(mean of the interpolated observed values,
+    root-mean variance of their columns) (:219-226; the reference's draw is unseeded -- ``seed`` feeds PCG64 here, as in the
+    product) and theta = 1 (:227)."""
+    n = X_interp_obs.shape[0]
+    mu0 = X_interp_obs.mean()
+    sd0 = (X_interp_obs.std(axis=0) ** 2).mean() ** 0.5
+    rng = np.random.Generator(np.random.PCG64(seed))
+    Xu0 = rng.normal(loc=mu0, scale=sd0, size=(n, len(unobserved_components)))
+    fn = lambda Xu, th: (lambda v: (v[0], [v[1], v[2]]))(gradient_matching_loss_and_grads(I, X_obs_smoothed, Xu, th, proper_order, unobserved_components, drift))
+    (Xu, th), losses = adam_minimise(fn, [Xu0, np.ones(P)], num_iters, lr)
+    return Xu, th, losses
+
+
 # Drifts f(t, X, theta) with analytic Jacobians (vignette.ipynb cell 3,
 # test_magi_script.py:19-45; SEIR-4 = the four data columns with S explicit)
 # --------------------------------------------------------------------------------------

@@ -4,7 +4,8 @@ cannot run there in seconds:
     sampler's single-phase kernel agree, (ii) the analytic gradient matches a central finite difference of the
     log posterior along random directions, (iii) C^-1 Kappa = I on random columns.
   * config 4 (alpha sweep): the ten thinned datasets x chains run end to end through the drop-in API.
-  * config 3: chains are independent of how they are batched (ids keyed Philox)."""
+  * config 3: chains are independent of how they are batched (ids keyed Philox), at N = 256 with 16 chains and at the
+    config's own size (N = 1024, 8 chains per GPU) with an oracle draw-for-draw check on the GPU-built matrices."""
 import os
 
 import numpy as np
@@ -70,19 +71,31 @@ def test_config5_sampler_runs_at_n8192():
     eng.close()
 
 
-def test_full_size_inverse_property_n2048():
+@pytest.mark.parametrize("N", [1024, 2048])
+def test_full_size_inverse_properties(N):
+    """C^-1 Kappa = I, m Kappa = p_Kappa and K^-1 K_ref = I on random columns at BASELINE sizes; K_ref = Kappa_pp +
+    p_Kappa Kappa^-1 p_Kappa is formed on the host from the GPU's Matern blocks (pinned against mpmath at small N).
+    K^-1 is the worst-conditioned product of the build: Schur complement, second Cholesky, second inverse."""
     from magi_v2_amd.engine import MagiEngine
-    N = 2048
+    EPS = np.finfo(float).eps
     I = np.arange(N) * 0.025
     eng = MagiEngine(0)
     C_inv, m, K_inv = eng.build_matrices(I, [0.05], [0.1], 2.01)
     Kap, pK, Kpp = eng.matern_blocks(I, 0.05, 0.1, 2.01)
     cols = np.random.default_rng(0).integers(0, N, 16)
+    cond = np.linalg.cond(Kap)
     R = C_inv[0] @ Kap[:, cols]
     R[cols, np.arange(16)] -= 1.0
-    cond = 2e6
-    assert np.abs(R).max() < 100 * cond * np.finfo(float).eps
-    assert np.abs(m[0] @ Kap[:, cols] - pK[:, cols]).max() < 100 * cond * np.finfo(float).eps * np.abs(pK).max()
+    assert np.abs(R).max() < 100 * cond * EPS
+    assert np.abs(m[0] @ Kap[:, cols] - pK[:, cols]).max() < 100 * cond * EPS * np.abs(pK).max()
+    m_ref = np.linalg.solve(Kap, pK.T).T                      # p_Kappa Kappa^-1   (Kappa_p = -p_Kappa, magi_v2.py:805)
+    K_ref = Kpp + m_ref @ pK
+    K_ref = 0.5 * (K_ref + K_ref.T)
+    condK = np.linalg.cond(K_ref)
+    R = K_inv[0] @ K_ref[:, cols]
+    R[cols, np.arange(16)] -= 1.0
+    assert np.abs(R).max() < 200 * cond * EPS * condK ** 0.5, (np.abs(R).max(), cond, condK)
+    assert np.abs(K_inv[0] - K_inv[0].T).max() == 0.0
     eng.close()
 
 
@@ -125,3 +138,63 @@ def test_config3_many_chains_sharded_equals_batched():
     _, _, tp_r1 = eng.sampler_samples()
     np.testing.assert_array_equal(tp_all[8:16], tp_r1)
     eng.close()
+
+
+def test_config3_at_size_n1024_eight_chains_per_gpu():
+    """BASELINE config 3 at its size: N = 1024 x 4 components, 8 independent chains on one GPU (rank r of 8 owns global chain
+    ids 8r .. 8r+7; here rank 1's block, i.e. ids that are not 0..7).
+      * the batch of 8 equals the same ids run as two batches of 4 and -- for two of them -- one at a time, bit for bit:
+        a chain's samples do not depend on what shares the GPU with it (placement independence, SURVEY 8e);
+      * chain 8 equals the CPU oracle draw for draw (tree depths, leapfrog counts, flags exact; states to 1e-8) on the
+        GPU-BUILT matrices pulled to the host -- the oracle comparison the small-N sampler tests make, at config 2/3's size."""
+    from magi_v2_amd.engine import MagiEngine
+    from magi_v2_amd.shard import chain_ids_for_rank
+    from oracle import magi_oracle as orc
+    N, P = 1024, 3
+    I, X_obs, truth, th = host.synthetic_seir(N, seed=0)
+    Xi = host.linear_interpolate(X_obs)
+    hp = host.hparams_initial(Xi)
+    N_ds, beta, idx, y = host.observation_bookkeeping(X_obs, X_obs)
+    Xhat = host.cubic_smoother(I, Xi)
+    LB = host.sigma_sqs_lower_bound(Xhat)
+    sp0, tp0 = host.softplus_inverse_inits(hp["sigma_sqs"], np.ones(P), LB)
+    eng = MagiEngine(0)
+    C_inv, m, K_inv = eng.build_matrices(I, hp["phi1s"], hp["phi2s"], 2.01)
+    eng.set_problem(Xi.mean(axis=0), N_ds.astype(np.float64), idx, y, beta, LB, "seir4")
+    ids = chain_ids_for_rank(1, 8, 64)
+    assert ids == list(range(8, 16))
+    burnin, results, seed = 3, 2, 77
+    cfg = eng.default_cfg(num_results=results, num_burnin_steps=burnin, stale_cache=0)
+    rep = lambda v, n: np.repeat(np.asarray(v)[None], n, axis=0)
+
+    def run(chain_ids):
+        n = len(chain_ids)
+        eng.sampler_init(cfg, rep(Xhat, n), rep(sp0, n), rep(tp0, n), seed=seed, chain_ids=chain_ids)
+        lf, _ = eng.sampler_run(burnin + results)
+        return eng.sampler_samples(), eng.sampler_diag(), lf
+
+    (X8, s8, t8), d8, lf8 = run(ids)
+    assert lf8 == d8.leapfrogs_taken.sum() and np.isfinite(X8).all()
+    assert len({tuple(r) for r in d8.leapfrogs_taken}) > 1 or not np.array_equal(t8[0], t8[1])        # the chains are distinct
+    for part in (ids[:4], ids[4:], [ids[2]], [ids[7]]):
+        (Xp, sp_, tp_), dp, _ = run(part)
+        sel = [ids.index(c) for c in part]
+        np.testing.assert_array_equal(Xp, X8[sel])
+        np.testing.assert_array_equal(tp_, t8[sel])
+        np.testing.assert_array_equal(dp.leapfrogs_taken, d8.leapfrogs_taken[sel])
+    eng.close()
+
+    pr = orc.Problem(I=I, mu=Xi.mean(axis=0), C_inv=C_inv, m=m, K_inv=K_inv, N_ds=N_ds.astype(np.float64), obs_idx=idx, y=y,
+                     beta=float(beta), LB=LB, drift="seir4", P=P)
+    trace = []
+    oX, osp, otp, info, _ = orc.sample_chain(pr, Xhat, hp["sigma_sqs"], np.ones(P), results, burnin, seed=seed, chain=ids[0],
+                                             stale_cache=False, trace=trace)
+    np.testing.assert_array_equal(d8.tree_depth[0], [r.depth for _, r, _ in trace])
+    np.testing.assert_array_equal(d8.leapfrogs_taken[0], [r.leapfrogs for _, r, _ in trace])
+    np.testing.assert_array_equal(d8.is_accepted[0], [int(r.is_accepted) for _, r, _ in trace])
+    np.testing.assert_array_equal(d8.has_divergence[0], [int(r.has_divergence) for _, r, _ in trace])
+    np.testing.assert_allclose(d8.step_size[0], [s for _, _, s in trace], rtol=1e-9)
+    np.testing.assert_allclose(d8.target_log_prob[0], [r.target_log_prob for _, r, _ in trace], rtol=1e-8)
+    np.testing.assert_allclose(X8[0], oX, rtol=0, atol=1e-8 * np.abs(oX).max())
+    np.testing.assert_allclose(t8[0], otp, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(s8[0], osp, rtol=1e-7, atol=1e-9)

@@ -113,6 +113,25 @@ def test_g4_logpost_and_gradient(golden_dir, tag):
             np.testing.assert_allclose(got, want, rtol=0, atol=1e-10 * np.abs(want).max())
 
 
+@pytest.mark.parametrize("tag", ["seir3_N161", "seir4_N81", "sirw_N41"])
+def test_torch_cpu_leg_matches_g4(golden_dir, tag):
+    """oracle/torch_cpu.py (the CPU baseline bench.py times: bmm + autograd restatement of magi_v2.py:308-348)
+    against the same G4 records."""
+    from oracle.torch_cpu import TorchLogPost
+    g = _load(golden_dir, f"g4_logpost_{tag}.npz")
+    probs = {}
+    for r in range(0, len(g["rec_logp"]), 2):
+        b = int(g["rec_band"][r])
+        if b not in probs:
+            probs[b] = TorchLogPost(problem_from_g4(g, None if b < 0 else b))
+        si = int(g["rec_state"][r])
+        lp, terms, gX, gs, gt = probs[b].value_and_grad(g["state_X"][si], g["state_sig_pre"][si], g["state_th_pre"][si], float(g["rec_temp"][r]))
+        np.testing.assert_allclose(terms, g["rec_terms"][r], rtol=1e-12)
+        assert abs(lp - g["rec_logp"][r]) <= 1e-12 * abs(g["rec_logp"][r])
+        for got, want in ((gX, g["rec_gX"][r]), (gs, g["rec_gsig"][r]), (gt, g["rec_gth"][r])):
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-10 * np.abs(want).max())
+
+
 def test_vignette_beta_constant(golden_dir):
     g = _load(golden_dir, "g4_logpost_seir3_N161.npz")
     # SURVEY section 8a4: beta = D*|I|/sum(N_d) = 3*161/243 for the vignette

@@ -160,15 +160,29 @@ def test_five_component_system_through_the_api():
 
 
 def test_seven_parameter_system_chain_matches_oracle():
-    """More than six parameters (P = 7): the specialised library is built with wider parameter blocks."""
+    """More than six parameters (P = 7): the specialised library is built with wider parameter blocks.  The chain starts at
+    the generating parameters with a small step so that it samples (from theta = 1 with TFP's step 0.1 this quadratic system
+    overflows on both sides, which would only compare divergence handling)."""
     eng, pr, Xhat, hp, truth = make_problem("competition7")
-    sp0, tp0 = host.softplus_inverse_inits(hp["sigma_sqs"], np.ones(7), pr.LB)
-    cfg = eng.default_cfg(num_results=3, num_burnin_steps=6, stale_cache=0)
+    sp0, tp0 = host.softplus_inverse_inits(hp["sigma_sqs"], truth, pr.LB)
+    cfg = eng.default_cfg(num_results=3, num_burnin_steps=6, stale_cache=0, step_size=2e-3)
     eng.sampler_init(cfg, Xhat, sp0, tp0, seed=31)
     eng.sampler_run(9)
     Xs, sp, tp = eng.sampler_samples()
+    d = eng.sampler_diag()
     trace = []
-    oX, osp, otp, info, _ = orc.sample_chain(pr, Xhat, hp["sigma_sqs"], np.ones(7), 3, 6, seed=31, stale_cache=False, trace=trace)
-    np.testing.assert_array_equal(eng.sampler_diag().leapfrogs_taken[0], [r.leapfrogs for _, r, _ in trace])
+    with np.errstate(all="raise"):                                         # no overflow / NaN anywhere on the oracle side
+        oX, osp, otp, info, _ = orc.sample_chain(pr, Xhat, hp["sigma_sqs"], truth, 3, 6, seed=31, step_size=2e-3, stale_cache=False, trace=trace)
+    assert np.isfinite(Xs).all() and np.isfinite(tp).all()
+    # (dual averaging overshoots twice while it adapts -- two divergent one-leaf trees -- then the chain samples: trees of 31 .. 255 leaves)
+    assert d.is_accepted[0].sum() >= 6 and d.leapfrogs_taken[0].max() >= 100 and d.has_divergence[0].sum() <= 2
+    np.testing.assert_array_equal(d.leapfrogs_taken[0], [r.leapfrogs for _, r, _ in trace])
+    np.testing.assert_array_equal(d.is_accepted[0], [int(r.is_accepted) for _, r, _ in trace])
+    np.testing.assert_array_equal(d.has_divergence[0], [int(r.has_divergence) for _, r, _ in trace])
+    lar = np.array([r.log_accept_ratio for _, r, _ in trace])
+    fin = np.isfinite(lar)
+    np.testing.assert_array_equal(np.isfinite(d.log_accept_ratio[0]), fin)
+    np.testing.assert_allclose(d.log_accept_ratio[0][fin], lar[fin], rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(tp[0], otp, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(Xs[0], oX, rtol=0, atol=1e-8 * np.abs(oX).max())
     eng.close()
