@@ -43,17 +43,18 @@ __device__ __forceinline__ TailVecs tail_vecs(const DevProblem& pb, double* vb) 
 
 // State-sized loops of the rare paths (subtree ends, transition ends), one workgroup over `dim` entries: written element by
 // element (`dst[e] = src[e]`) every iteration is its own memory round trip -- DB elements' loads are issued together instead.
-constexpr int DB = 4;
+constexpr int DB = 4;        // (loops that keep seven vectors' elements in registers)
+constexpr int DBC = 6;       // copies, sample set-up, doubling set-up: fewer vectors, more elements in flight
 __device__ __forceinline__ void copy2_batched(double* d0, const double* s0, double* d1, const double* s1, int dim) {
-    for (int e0 = threadIdx.x; e0 < dim; e0 += DB * (int)blockDim.x) {
-        double a[DB], b[DB];
+    for (int e0 = threadIdx.x; e0 < dim; e0 += DBC * (int)blockDim.x) {
+        double a[DBC], b[DBC];
 #pragma unroll
-        for (int u = 0; u < DB; ++u) {
+        for (int u = 0; u < DBC; ++u) {
             const int e = e0 + u * (int)blockDim.x;
             if (e < dim) { a[u] = s0[e]; if (s1) b[u] = s1[e]; }
         }
 #pragma unroll
-        for (int u = 0; u < DB; ++u) {
+        for (int u = 0; u < DBC; ++u) {
             const int e = e0 + u * (int)blockDim.x;
             if (e < dim) { d0[e] = a[u]; if (d1) d1[e] = b[u]; }
         }
@@ -283,10 +284,11 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
             const double* po_ = (c.dir > 0) ? v.pL : v.pR;    // the other end
             double dots[2] = {0.0, 0.0};
             const bool take_leaf = accept_leaf || hmc;
-            for (int e0 = tid; e0 < dim; e0 += DB * (int)blockDim.x) {       // DB elements' loads in flight, then their stores
-                double qv[DB], gv[DB], sq[DB], sg[DB], pn[DB], rr[DB], po[DB];
+            constexpr int DBM = 4;
+            for (int e0 = tid; e0 < dim; e0 += DBM * (int)blockDim.x) {       // DBM elements' loads in flight, then their stores
+                double qv[DBM], gv[DBM], sq[DBM], sg[DBM], pn[DBM], rr[DBM], po[DBM];
 #pragma unroll
-                for (int u = 0; u < DB; ++u) {
+                for (int u = 0; u < DBM; ++u) {
                     const int e = e0 + u * (int)blockDim.x;
                     if (e < dim) {
                         qv[u] = qcur[e]; gv[u] = v.g[e];
@@ -298,7 +300,7 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < DB; ++u) {
+                for (int u = 0; u < DBM; ++u) {
                     const int e = e0 + u * (int)blockDim.x;
                     if (e < dim) {
                         if (choose) { v.candq[e] = sq[u]; v.candg[e] = sg[u]; }
@@ -373,22 +375,29 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
         __syncthreads();
         if (tid == 0) shs[4] = cfg.anneal ? temperature(c.k, cfg.min_temp) : 1.0;
         double pp0[1] = {0.0};
-        for (int e0 = tid; e0 < dim; e0 += DB * (int)blockDim.x) {
-            double qq[DB], gg[DB];
+        // (pair j = elements 2 j, 2 j + 1 of the state: one Philox block, one log / sqrt per pair; 16-B accesses -- every vector is
+        //  16-B aligned and padded to an even length)
+        constexpr int DBP = 4;
+        const int npair = (dim + 1) >> 1;
+        for (int j0 = tid; j0 < npair; j0 += DBP * (int)blockDim.x) {
+            double2 qq[DBP], gg[DBP];
 #pragma unroll
-            for (int u = 0; u < DB; ++u) {
-                const int e = e0 + u * (int)blockDim.x;
-                if (e < dim) { qq[u] = v.candq[e]; gg[u] = v.candg[e]; }
+            for (int u = 0; u < DBP; ++u) {
+                const int j = j0 + u * (int)blockDim.x;
+                if (j < npair) { qq[u] = reinterpret_cast<const double2*>(v.candq)[j]; gg[u] = reinterpret_cast<const double2*>(v.candg)[j]; }
             }
 #pragma unroll
-            for (int u = 0; u < DB; ++u) {
-                const int e = e0 + u * (int)blockDim.x;
-                if (e < dim) {
-                    const double z = rng_normal_elem((unsigned)e, (unsigned)c.k, (unsigned)c.chain_id, cfg.seed);
-                    pp0[0] = fma(z, z, pp0[0]);
-                    v.pL[e] = z; v.pR[e] = z; v.rho[e] = z;
-                    v.qL[e] = qq[u]; v.qR[e] = qq[u];
-                    v.gL[e] = gg[u]; v.gR[e] = gg[u];
+            for (int u = 0; u < DBP; ++u) {
+                const int j = j0 + u * (int)blockDim.x;
+                if (j < npair) {
+                    double2 z;
+                    rng_normal_pair((unsigned)j, (unsigned)c.k, (unsigned)c.chain_id, cfg.seed, z.x, z.y);
+                    if (2 * j + 1 >= dim) z.y = 0.0;                 // (odd dim: the pad entry stays zero)
+                    pp0[0] = fma(z.x, z.x, pp0[0]);
+                    pp0[0] = fma(z.y, z.y, pp0[0]);
+                    reinterpret_cast<double2*>(v.pL)[j] = z; reinterpret_cast<double2*>(v.pR)[j] = z; reinterpret_cast<double2*>(v.rho)[j] = z;
+                    reinterpret_cast<double2*>(v.qL)[j] = qq[u]; reinterpret_cast<double2*>(v.qR)[j] = qq[u];
+                    reinterpret_cast<double2*>(v.gL)[j] = gg[u]; reinterpret_cast<double2*>(v.gR)[j] = gg[u];
                 }
             }
         }
@@ -426,15 +435,15 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
         c.cur ^= 1;
         double* qw = vb + (size_t)(V_Q + c.cur) * sv;
         double* pw = vb + (size_t)(V_P + c.cur) * sv;
-        for (int e0 = tid; e0 < dim; e0 += DB * (int)blockDim.x) {
-            double p0[DB], g0[DB], q0[DB];
+        for (int e0 = tid; e0 < dim; e0 += DBC * (int)blockDim.x) {
+            double p0[DBC], g0[DBC], q0[DBC];
 #pragma unroll
-            for (int u = 0; u < DB; ++u) {
+            for (int u = 0; u < DBC; ++u) {
                 const int e = e0 + u * (int)blockDim.x;
                 if (e < dim) { p0[u] = pe[e]; g0[u] = ge[e]; q0[u] = qe[e]; }
             }
 #pragma unroll
-            for (int u = 0; u < DB; ++u) {
+            for (int u = 0; u < DBC; ++u) {
                 const int e = e0 + u * (int)blockDim.x;
                 if (e < dim) {
                     const double ph = p0[u] + hs * g0[u];

@@ -5,6 +5,8 @@
 // is the kernel pair [k_stream, k_point]; the decisions of slot s - 1 (decide.h) ride in k_stream(s) as one extra
 // workgroup per chain, off the critical path, and the stream itself assumes "same subtree, next leaf".
 // (reference arithmetic: magi_v2.py:308-348)
+#include <cstdlib>
+
 #include "magi_internal.h"
 #include "leap_reduce.h"
 #include "leap_point.h"
@@ -259,6 +261,254 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
 #endif
 }
 
+// ---- multi-chain streaming kernel on the matrix cores -----------------------------------------------------------------------
+// For 3 .. 16 chains per pass the chains are the 16-wide dimension of v_mfma_f64_16x16x4_f64: a 16 x 16 piece S of the operator
+// block gives   row-type  (S v)[r, chain]   = sum_c S[r][c] V[c][chain]   and   column-type (S^T w)[c, chain] = sum_r S[r][c] W[r][chain]
+// as 4 + 4 MFMAs whose accumulation IS the reduction -- no per-chain butterflies, and every chain shares every matrix byte.
+// The two products contract over different tile indices, so the tile is needed in two lane layouts (an MFMA operand has its
+// contraction index on lane >> 4 and its free index on lane & 15):
+//   * the global load is shaped for the column-type product -- one instruction = 4 rows x 32 columns, lane = (row j = lane >> 4,
+//     column pair i = lane & 15): four fully used 256-B segments -- and feeds those MFMAs straight from the registers;
+//   * the same registers are written to a wave-private 16 x 32 LDS patch (272-B rows) and read back transposed (lane = (row i,
+//     column pair j)) for the row-type MFMAs; wave-private, so no barrier: LDS operations of one wave execute in order.
+// Wave w owns rows [32 w, 32 w + 32) of the block = 2 chunks of 16 rows x 4 column groups of 32: eight steps, a ring of
+// MC_RING steps' loads in flight.
+// The operand vectors xc = X - mu and f = drift(X, theta) of all chains are formed ONCE per slot by k_operands (each of the
+// 544 block workgroups gathering 16 chains x D components itself would move as many bytes as the operator blocks) in the
+// layout [xc | f][d][grid index][16 chains]: a block's column slice is one contiguous 16 KB piece (-> LDS), a wave's row slice
+// is read straight into the MFMA fragment registers.
+constexpr int MC = 16;                                   // chain columns per pass
+constexpr int MC_PITCH = 34;                             // doubles per staged row: 32 columns + 2 (272 B: conflict-free transposed reads)
+constexpr int MC_SM_V = 0, MC_SM_ST = MC_SM_V + MAGI_TB * MC, MC_SM_CS = MC_SM_ST + 4 * 16 * MC_PITCH, MC_SM_DOUBLES = MC_SM_CS + MC * MAGI_TB;
+using mc_d4 = __attribute__((ext_vector_type(4))) double;
+#ifndef MAGI_MC_RING
+#define MAGI_MC_RING 5
+#endif
+constexpr int MC_RING = MAGI_MC_RING;                    // steps of tile loads in flight per wave (ring of register buffers)
+
+// sel: 0 = xc, 1 = f in row order [grid index][16 chains] (fragment order of the column-type MFMAs' chain operand);
+//      2 = xc, 3 = f in column-pair order [grid index / 2][16 chains][2] (the row-type MFMAs read two adjacent columns at once)
+__host__ __device__ inline size_t opv_off(const DevProblem& pb, int group, int sel, int d) {
+    return (((size_t)group * 4 + sel) * pb.D + d) * (size_t)pb.Np * MC;
+}
+
+// operand vectors of slot `parity` for every chain: what k_stream assumes per workgroup (the state the last plan leaves to be
+// evaluated; theta' derived from the point phase's partial sums with the decisions' own functions), once per chain and point.
+// grid (Np / 16, groups), 256 threads = (chain t & 15, point t >> 4).
+template <int DRIFT>
+__global__ __launch_bounds__(256) void k_operands(DevProblem pb, DevChains ch, int parity) {
+    using DR = DriftT<DRIFT>;
+    constexpr int D = DR::D, P = DR::P;
+    static_assert(P <= 8, "theta slots");
+    __shared__ double th_s[MC * 8];
+    const int all_done = ch.gctl->all_done;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lj = lane >> 4;
+    const int c0 = blockIdx.y * MC, nch = ch.n_chains;
+    {
+        double rows[4][P];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cc = min(c0 + wave * 4 + k, nch - 1);
+            const double* part = ch.part + (size_t)cc * PART_K * ch.n_wg;
+#pragma unroll
+            for (int r = 0; r < P; ++r) rows[k][r] = (lane < ch.n_wg) ? part[(size_t)(PK_TP + r) * ch.n_wg + lane] : 0.0;
+            for (int w0 = 64; w0 < ch.n_wg; w0 += 64) {
+#pragma unroll
+                for (int r = 0; r < P; ++r) if (w0 + lane < ch.n_wg) rows[k][r] += part[(size_t)(PK_TP + r) * ch.n_wg + w0 + lane];
+            }
+        }
+        // this lane's own (chain 4 wave + lj, parameter li)
+        const int cc = min(c0 + wave * 4 + lj, nch - 1);
+        const LeafPlan* lp = ch.plan + (size_t)(parity ^ 1) * nch + cc;
+        const int lcur = lp->cur;
+        const double lhs = lp->hs, leps = lp->eps;
+        const bool lder = lp->active && !lp->skip && lp->leaf;
+        const int e = pb.ND + D + min(li, P - 1);
+        const double* vb = ch.vec + vec_off(pb, cc, 0);
+        const double qv = (vb + (size_t)(V_Q + lcur) * pb.dimp)[e], pv = (vb + (size_t)(V_P + lcur) * pb.dimp)[e];
+        const double parv = ch.par[(size_t)cc * PAR_COUNT + PAR_TH + min(li, P - 1)];
+        double tpp = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < P; ++r) {
+                const double sres = wave_sum(rows[k][r]);
+                if (lj == k && li == r) tpp = sres;
+            }
+        double thp = parv;
+        if (lder && li < P) {
+            const double ex = m_exp(qv);
+            const double sg = ex / (1.0 + ex);                       // == par[PAR_SGT] of that state (compute_par_entry)
+            const double qnx = next_entry_pre(pv, qv, lhs, leps, theta_entry_grad(pb.beta_inv, tpp, sg));
+            thp = m_log(1.0 + m_exp(qnx));                           // == par'[PAR_TH] (compute_par_entry)
+        }
+        if (li < P) th_s[(wave * 4 + lj) * 8 + li] = thp;
+    }
+    if (all_done) return;
+    __syncthreads();
+    const int c = t & 15, cc = min(c0 + c, nch - 1), i = blockIdx.x * 16 + (t >> 4);
+    const LeafPlan* lp = ch.plan + (size_t)(parity ^ 1) * nch + cc;
+    const int buf = (lp->skip || !lp->leaf) ? lp->cur : (lp->cur ^ 1);
+    const double* q = ch.vec + vec_off(pb, cc, V_Q + buf);
+    const bool valid = (c0 + c < nch) && i < pb.N;
+    double x[D], th[P], f[D];
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) x[dd] = q[dd * pb.N + min(i, pb.N - 1)];
+#pragma unroll
+    for (int k = 0; k < P; ++k) th[k] = th_s[c * 8 + k];
+    DR::f(x, th, f);
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) {
+        const double xcv = valid ? x[dd] - pb.mu[dd] : 0.0, fv = valid ? f[dd] : 0.0;
+        ch.opv[opv_off(pb, blockIdx.y, 0, dd) + (size_t)i * MC + c] = xcv;
+        ch.opv[opv_off(pb, blockIdx.y, 1, dd) + (size_t)i * MC + c] = fv;
+        ch.opv[opv_off(pb, blockIdx.y, 2, dd) + ((size_t)(i >> 1) * MC + c) * 2 + (i & 1)] = xcv;
+        ch.opv[opv_off(pb, blockIdx.y, 3, dd) + ((size_t)(i >> 1) * MC + c) * 2 + (i & 1)] = fv;
+    }
+}
+
+template <int DRIFT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_stream_mc(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
+    constexpr int D = DriftT<DRIFT>::D, TB = MAGI_TB;
+    const int all_done = ch.gctl->all_done;
+    kernarg_prefetch<sizeof(DevProblem) + sizeof(DevChains) + sizeof(SamplerCfgDev) + sizeof(int)>();
+    const int c0 = blockIdx.y * MC;
+    // one LDS block: the stream workgroups carve their operand image and staging patches out of it, the decision workgroups their scratch
+    __shared__ __attribute__((aligned(16))) double smem[MC_SM_DOUBLES];
+    const int n_dec = (int)gridDim.x - pb.n_tasks;
+    if ((int)blockIdx.x < n_dec) {
+        double* dsh = smem;                                   // 25 * 16
+        double* dshs = dsh + 25 * 16;                         // 24
+        double* s_par = dshs + 24;                            // PAR_COUNT
+        double* s_ops = s_par + PAR_COUNT;                    // OPS_COUNT * OPS_W
+        double* s_cst = s_ops + OPS_COUNT * OPS_W;            // 2 * MAGI_MAX_D
+        int* s_g = reinterpret_cast<int*>(s_cst + 2 * MAGI_MAX_D);
+        ChainCtl* s_ctl = reinterpret_cast<ChainCtl*>(s_cst + 2 * MAGI_MAX_D + 2);
+        static_assert(25 * 16 + 24 + PAR_COUNT + OPS_COUNT * OPS_W + 2 * MAGI_MAX_D + 2 + (sizeof(ChainCtl) + 7) / 8 <= MC_SM_DOUBLES, "decision scratch");
+        const int chain = c0 + (int)blockIdx.x;
+        if (chain < ch.n_chains) decide_block<DRIFT>(pb, ch, cfg, chain, parity, all_done, dsh, dshs, s_ctl, s_g, s_par, s_ops, s_cst);
+        return;
+    }
+    const double2* vimg = reinterpret_cast<const double2*>(smem + MC_SM_V);    // [column pair][chain] = (v[2 cp], v[2 cp + 1]) of the block's column slice
+    double* colsum = smem + MC_SM_CS;                                            // [chain][column]: running column-type sums
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    double* stage = smem + MC_SM_ST + wave * 16 * MC_PITCH;
+    const int tix = (int)blockIdx.x - n_dec;
+    typedef const int __attribute__((address_space(4))) * const_int_ptr;
+    const_int_ptr tk = (const_int_ptr)(unsigned long long)(pb.tasks + 4 * (size_t)tix);
+    const int d = tk[0], kind = tk[1], bi = tk[2], bj = tk[3];
+    const int nch = ch.n_chains;
+
+    // Tile stream.  Wave w owns rows [32 w, 32 w + 32); its eight steps are ordered by column group: phase p = s >> 1 works on
+    // group g = (w + p) & 3, chunk s & 1.  In every phase the four waves work on four DIFFERENT column groups, so the running
+    // column-type sums of a group live in LDS and are owned by one wave at a time (fixed hand-over order: deterministic), and a
+    // wave carries the accumulators of ONE group instead of four -- the registers go to the load ring instead.
+    // lane = (row 4 q + lj, column pair li) of a 16 x 32 piece.
+    const double2* A = reinterpret_cast<const double2*>(pb.tiles + (size_t)tix * TB * TB) + (size_t)(32 * wave + lj) * (TB / 2) + li;
+    auto ld = [&](int s, int q) { return A[(size_t)(16 * (s & 1) + 4 * q) * (TB / 2) + 16 * ((wave + (s >> 1)) & 3)]; };
+    double2 tl[MC_RING][4];
+#pragma unroll
+    for (int s = 0; s < MC_RING - 1; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tl[s][q] = ld(s, q);
+    // operand slices (k_operands): columns of block column bj -> LDS (16 KB, copied as is); this wave's rows of block row bi ->
+    // fragment registers
+    const double2* vsrc = reinterpret_cast<const double2*>(ch.opv + opv_off(pb, blockIdx.y, kind == TK_FK ? 3 : 2, d) + (size_t)bj * TB * MC);
+    const double* wsrc = ch.opv + opv_off(pb, blockIdx.y, kind != TK_FH ? 1 : 0, d) + (size_t)(bi * TB + 32 * wave) * MC;
+    double2 vv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vv[k] = vsrc[(size_t)k * 256 + t];
+    double wf[2][4];                                                       // W[32 wave + 16 cidx + 4 q + lj][chain li]
+#pragma unroll
+    for (int cidx = 0; cidx < 2; ++cidx)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wf[cidx][q] = wsrc[(size_t)(16 * cidx + 4 * q + lj) * MC + li];
+    if (all_done) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) reinterpret_cast<double2*>(smem + MC_SM_V)[k * 256 + t] = vv[k];
+    __syncthreads();                 // operand image complete
+
+    const bool coltype = (kind == TK_FE) || (bi != bj);      // (diagonal blocks of FH / FK are stored full: complete by rows)
+    mc_d4 accc[2], accr[2];
+    accr[0] = mc_d4{0.0, 0.0, 0.0, 0.0}; accr[1] = mc_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int cidx = s & 1, g = (wave + (s >> 1)) & 3;
+        if (s + MC_RING - 1 < 8) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tl[(s + MC_RING - 1) % MC_RING][q] = ld(s + MC_RING - 1, q);
+        }
+        double2 (&tt)[4] = tl[s % MC_RING];
+        if (cidx == 0) {
+            // take over the column sums of group g (register r of lane (li, lj) = chain lj + 4 r, columns 32 g + 2 li + {0, 1})
+            if (s == 0 || !coltype) { accc[0] = mc_d4{0.0, 0.0, 0.0, 0.0}; accc[1] = mc_d4{0.0, 0.0, 0.0, 0.0}; }
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double2 u = *reinterpret_cast<const double2*>(&colsum[(lj + 4 * r) * TB + 32 * g + 2 * li]);
+                    accc[0][r] = u.x; accc[1][r] = u.y;
+                }
+            }
+        }
+        // column-type: A = W^T fragment (m = chain, k = row), B = tile (k = row, n = column)
+        if (coltype) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                accc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[cidx][q], tt[q].x, accc[0], 0, 0, 0);
+                accc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[cidx][q], tt[q].y, accc[1], 0, 0, 0);
+            }
+        }
+        // transpose through the wave's LDS patch
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(&stage[(4 * q + lj) * MC_PITCH + 2 * li]) = tt[q];
+        // row-type: A = V^T fragment (m = chain, k = column), B = tile (k = column, n = row)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double2 b = *reinterpret_cast<const double2*>(&stage[li * MC_PITCH + 2 * (4 * q + lj)]);
+            const double2 v = vimg[(16 * g + 4 * q + lj) * MC + li];
+            accr[cidx] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, b.x, accr[cidx], 0, 0, 0);
+            accr[cidx] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, b.y, accr[cidx], 0, 0, 0);
+        }
+        if (cidx == 1 && coltype) {
+            // hand the column sums of group g on: the next phase's owner of g is another wave
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<double2*>(&colsum[(lj + 4 * r) * TB + 32 * g + 2 * li]) = double2{accc[0][r], accc[1][r]};
+            __syncthreads();
+        }
+        __builtin_amdgcn_sched_barrier(0);      // (keeps the next steps' fragment reads out of this one: they would not fit the register file)
+    }
+
+    // ---- partials.  Accumulator layout: register r of lane (li, lj) = chain lj + 4 r, free index li. ----
+    const int rvec = kind == TK_FH ? TV_HX : kind == TK_FK ? TV_KF : TV_EX;
+    const int cvec = kind == TK_FH ? TV_HX : kind == TK_FK ? TV_KF : TV_ETF;
+    const size_t cstride = (size_t)4 * D * pb.nb * pb.Np;
+    // row-type: block row bi, slot bj; rows 32 wave + 16 cidx + li
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = lj + 4 * r;
+        const bool act = (c0 + c < nch) && ch.plan[(size_t)(parity ^ 1) * nch + min(c0 + c, nch - 1)].active != 0;
+#pragma unroll
+        for (int cidx = 0; cidx < 2; ++cidx)
+            if (act)
+                ch.tpart[(size_t)(c0 + c) * cstride + ((size_t)(rvec * D + d) * pb.nb + bj) * pb.Np + bi * TB + 32 * wave + 16 * cidx + li] = accr[cidx][r];
+    }
+    if (!coltype) return;
+    // column-type: complete in LDS after the last phase's barrier; thread = (chain t >> 4, eight columns)
+    {
+        const int c = t >> 4, col = 8 * (t & 15);
+        const bool act = (c0 + c < nch) && ch.plan[(size_t)(parity ^ 1) * nch + min(c0 + c, nch - 1)].active != 0;
+        if (act) {
+            double2* dst = reinterpret_cast<double2*>(&ch.tpart[(size_t)(c0 + c) * cstride + ((size_t)(cvec * D + d) * pb.nb + bi) * pb.Np + bj * TB + col]);
+            const double2* src = reinterpret_cast<const double2*>(&colsum[c * TB + col]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dst[k] = src[k];
+        }
+    }
+}
+
 // ---- point kernel: the elementwise half of slot `parity` (leap_point.h), N / 16 workgroups per chain -------------------------
 template <int DRIFT>
 __global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains ch, int parity) {
@@ -339,7 +589,34 @@ int launch_stream_nc(magi_handle* h, int n_chains, int parity, bool with_decisio
 
 int magi_leap_wgs(const DevProblem& pb) { return (pb.N + PT_POINTS - 1) / PT_POINTS; }
 
+// which streaming kernel serves >= 3 chains per GPU: the matrix-core kernel (default) or the VALU kernel in groups of four
+// (MAGI_STREAM_KERNEL=valu, for A/B measurements)
+static bool use_mc_kernel() {
+    static const bool v = [] { const char* e = getenv("MAGI_STREAM_KERNEL"); return !(e && std::string(e) == "valu"); }();
+    return v;
+}
+
+template <int DRIFT>
+int launch_stream_mc(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s) {
+    const DevProblem& pb = h->pb;
+    const int groups = (n_chains + MC - 1) / MC;
+    hipLaunchKernelGGL((k_operands<DRIFT>), dim3(pb.Np / 16, groups), dim3(256), 0, s, pb, h->ch, parity);
+    static const int limit = [] { const char* e = getenv("MAGI_MC_LIMIT"); return e ? atoi(e) : 0; }();     // dev: time a truncated grid (wrong results)
+    DevProblem pbl = pb;
+    if (limit > 0 && limit < pb.n_tasks) pbl.n_tasks = limit;
+    const dim3 grid(pbl.n_tasks + (with_decisions ? MC : 0), groups);
+    hipLaunchKernelGGL((k_stream_mc<DRIFT>), grid, dim3(256), 0, s, pbl, h->ch, h->cfg, parity);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("stream (matrix-core) launch: ") + hipGetErrorString(e));
+    return MAGI_OK;
+}
+
 int magi_launch_stream(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s) {
+    if (n_chains >= 3 && use_mc_kernel()) {
+#define MAGI_CALL(DR) return launch_stream_mc<DR>(h, n_chains, parity, with_decisions, s)
+        MAGI_DRIFT_DISPATCH(h->pb.drift, MAGI_CALL);
+#undef MAGI_CALL
+    }
     if (n_chains >= 3) return launch_stream_nc<4>(h, n_chains, parity, with_decisions, s);
     if (n_chains == 2) return launch_stream_nc<2>(h, n_chains, parity, with_decisions, s);
     return launch_stream_nc<1>(h, n_chains, parity, with_decisions, s);

@@ -176,6 +176,7 @@ struct DevChains {
     double* part;         // [n_chains][PART_K][n_wg] partial sums of the point kernel
     int n_wg;             // workgroups along the grid axis of k_point
     double* tpart;        // [n_chains][4 (hx, ex, etf, kf)][D][nb][Np] block partials of the streaming kernel
+    double* opv;          // [ceil(n_chains / 16)][4 (xc, f: row order; xc, f: column-pair order)][D][Np][16] operand vectors of the matrix-core streaming kernel (leap.hip)
     double* par;          // [n_chains][PAR_COUNT] transformed parameters of the state in V_Q
     GlobalCtl* gctl;
     int n_chains;
@@ -277,6 +278,17 @@ __device__ inline double rng_normal_elem(unsigned int e, unsigned int step, unsi
     double rad = sqrt(-2.0 * m_log(u1));
     double ang = 2.0 * 3.141592653589793 * u2;
     return (e & 1) ? rad * sin(ang) : rad * cos(ang);
+}
+
+// both normals of Philox pair j (elements 2 j and 2 j + 1): the same values as rng_normal_elem, with the Philox block, the
+// logarithm and the square root evaluated once per pair instead of once per element
+__device__ inline void rng_normal_pair(unsigned int j, unsigned int step, unsigned int chain, unsigned long long key, double& z0, double& z1) {
+    Philox4 r = philox4x32_10(j, step, chain, STREAM_MOMENTUM, key);
+    double u1 = u01_53(r.x, r.y), u2 = u01_53(r.z, r.w);
+    double rad = sqrt(-2.0 * m_log(u1));
+    double ang = 2.0 * 3.141592653589793 * u2;
+    z0 = rad * cos(ang);
+    z1 = rad * sin(ang);
 }
 
 // ------------------------------------------------------------------------------------------

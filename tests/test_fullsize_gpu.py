@@ -143,8 +143,9 @@ def test_config3_many_chains_sharded_equals_batched():
 def test_config3_at_size_n1024_eight_chains_per_gpu():
     """BASELINE config 3 at its size: N = 1024 x 4 components, 8 independent chains on one GPU (rank r of 8 owns global chain
     ids 8r .. 8r+7; here rank 1's block, i.e. ids that are not 0..7).
-      * the batch of 8 equals the same ids run as two batches of 4 and -- for two of them -- one at a time, bit for bit:
-        a chain's samples do not depend on what shares the GPU with it (placement independence, SURVEY 8e);
+      * the batch of 8 equals the same ids run as batches of 4, 4 and 3 bit for bit, and -- for two of them -- one at a time
+        (the one-chain kernel sums in another order: same tree sizes, states to 1e-8): a chain's samples do not depend on
+        what shares the GPU with it (placement independence, SURVEY 8e);
       * chain 8 equals the CPU oracle draw for draw (tree depths, leapfrog counts, flags exact; states to 1e-8) on the
         GPU-BUILT matrices pulled to the host -- the oracle comparison the small-N sampler tests make, at config 2/3's size."""
     from magi_v2_amd.engine import MagiEngine
@@ -163,8 +164,10 @@ def test_config3_at_size_n1024_eight_chains_per_gpu():
     eng.set_problem(Xi.mean(axis=0), N_ds.astype(np.float64), idx, y, beta, LB, "seir4")
     ids = chain_ids_for_rank(1, 8, 64)
     assert ids == list(range(8, 16))
-    burnin, results, seed = 3, 2, 77
-    cfg = eng.default_cfg(num_results=results, num_burnin_steps=burnin, stale_cache=0)
+    # (from TFP's initial step 0.1 every early proposal on this grid diverges at its first leaf and the chains never move:
+    #  start at the step size the adaptation settles at, so that the transitions build trees and accept states)
+    burnin, results, seed, step0 = 2, 1, 77, 1e-3
+    cfg = eng.default_cfg(num_results=results, num_burnin_steps=burnin, stale_cache=0, step_size=step0)
     rep = lambda v, n: np.repeat(np.asarray(v)[None], n, axis=0)
 
     def run(chain_ids):
@@ -175,20 +178,25 @@ def test_config3_at_size_n1024_eight_chains_per_gpu():
 
     (X8, s8, t8), d8, lf8 = run(ids)
     assert lf8 == d8.leapfrogs_taken.sum() and np.isfinite(X8).all()
-    assert len({tuple(r) for r in d8.leapfrogs_taken}) > 1 or not np.array_equal(t8[0], t8[1])        # the chains are distinct
-    for part in (ids[:4], ids[4:], [ids[2]], [ids[7]]):
+    assert d8.leapfrogs_taken.max() >= 15 and d8.is_accepted.sum() >= 8 and not np.array_equal(t8[0], t8[1])      # trees grow, states move, chains differ
+    for part in (ids[:4], ids[4:], ids[5:8], [ids[2]], [ids[7]]):
         (Xp, sp_, tp_), dp, _ = run(part)
         sel = [ids.index(c) for c in part]
-        np.testing.assert_array_equal(Xp, X8[sel])
-        np.testing.assert_array_equal(tp_, t8[sel])
         np.testing.assert_array_equal(dp.leapfrogs_taken, d8.leapfrogs_taken[sel])
+        np.testing.assert_array_equal(dp.tree_depth, d8.tree_depth[sel])
+        if len(part) >= 3:          # batches of three or more chains run the same (matrix-core) kernel: bit for bit
+            np.testing.assert_array_equal(Xp, X8[sel])
+            np.testing.assert_array_equal(tp_, t8[sel])
+        else:                       # one or two chains run the one-chain kernels: another summation order, same chain to rounding
+            np.testing.assert_allclose(Xp, X8[sel], rtol=0, atol=1e-8 * np.abs(X8).max())
+            np.testing.assert_allclose(tp_, t8[sel], rtol=1e-7, atol=1e-9)
     eng.close()
 
     pr = orc.Problem(I=I, mu=Xi.mean(axis=0), C_inv=C_inv, m=m, K_inv=K_inv, N_ds=N_ds.astype(np.float64), obs_idx=idx, y=y,
                      beta=float(beta), LB=LB, drift="seir4", P=P)
     trace = []
     oX, osp, otp, info, _ = orc.sample_chain(pr, Xhat, hp["sigma_sqs"], np.ones(P), results, burnin, seed=seed, chain=ids[0],
-                                             stale_cache=False, trace=trace)
+                                             step_size=step0, stale_cache=False, trace=trace)
     np.testing.assert_array_equal(d8.tree_depth[0], [r.depth for _, r, _ in trace])
     np.testing.assert_array_equal(d8.leapfrogs_taken[0], [r.leapfrogs for _, r, _ in trace])
     np.testing.assert_array_equal(d8.is_accepted[0], [int(r.is_accepted) for _, r, _ in trace])
