@@ -179,8 +179,12 @@ struct GemmArgs {
     double alpha, beta;
     int lower_only;    // 1: skip tiles strictly above the block diagonal (m0 + 127 < n0)
     int kmode;         // 0: k in [0, K) ; 1: k >= min-aligned max(m0, n0) (A, B "lower" in (k, m)) ;
-                       // 2: k < m0 + 128 (A lower-triangular in (m, k)) ; 3: k >= n0 (B(n,k) zero for k < n)
+                       // 2: k < m0 + 128 (A lower-triangular in (m, k)) ; 3: k >= n0 (B(n,k) zero for k < n) ;
+                       // 4: k < n0 + 128 (B(n,k) zero for k > n)
     long batchA, batchB, batchC;   // element strides between grid.z batches
+    int remap;                     // set by launch_gemm: XCD-aware super-block tile order (large tile grids)
+    int zinner;                    // > 0: grid.z = zinner x outer; batch* step the inner index, batch*2 the outer one
+    long batchA2, batchB2, batchC2;
 };
 
 constexpr int GT = 128, GK = 16, GP = 129;   // odd pitch: the k-fast staging stores of a 16-lane group hit 16 distinct bank pairs
@@ -310,19 +314,53 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, double* C, int 
 #ifndef MAGI_GEMM_OCC
 #define MAGI_GEMM_OCC 2      // 250 VGPRs, two workgroups per CU: one stages while the other issues MFMAs (1 -> 0.53, 2 -> 0.76 of the fp64 MFMA peak at N = 8192)
 #endif
+// CLS only names the instantiation (BuildClass below): the per-class rows of a rocprofv3 kernel trace of the matrix build
+template <int CLS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAGI_GEMM_OCC, MAGI_GEMM_OCC))) void k_gemm_f64(GemmArgs g) {
     __shared__ double As[GK * GP], Bs[GK * GP];
-    // kmode 2 tiles get longer k ranges with growing m0: dispatch the long ones first so the short ones fill the tail
-    const int by = (g.kmode == 2) ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
-    const int m0 = by * GT, n0 = blockIdx.x * GT;
+    // Tile of this workgroup.  The hardware deals workgroups to the 8 XCDs round-robin on the linear id, and an XCD holds 64 of them
+    // (32 CUs x 2): XCD x takes the 8 x 8 SUPER-BLOCKS u = x, x + 8, ... of the tile grid, one at a time -- its 64 resident tiles
+    // then share 8 row panels of A and 8 column panels of B through its own L2 in step, whatever the shape of the active region
+    // (lower-only / triangular k ranges otherwise scatter the co-resident tiles and lose that reuse: 0.55 instead of 0.9 of the
+    // MFMA peak).  Lower-only launches enumerate the lower super-blocks only.
+    const int tY = (g.M + GT - 1) / GT, tX = (g.N + GT - 1) / GT, sY = (tY + 7) >> 3, sX = (tX + 7) >> 3;
+    int by, bx;
+    if (!g.remap) {           // small tile grids (fewer than three super-blocks per XCD): plain row-major tiles, long k ranges first
+        by = (int)blockIdx.x / tX; bx = (int)blockIdx.x - by * tX;
+        if (g.kmode == 2) by = tY - 1 - by;
+        if (g.kmode == 4) bx = tX - 1 - bx;
+    } else {
+    const int i = (int)blockIdx.x, j = i >> 3;
+    const int u = (j >> 6) * 8 + (((i & 7) + (j >> 6)) & 7), w = j & 63;      // (rotated: an XCD must not keep ONE super-column -- k ranges
+                                                                               //  that depend on the column would all be long on one XCD)
+    int sy, sx;
+    if (g.lower_only) {
+        sy = (int)((sqrtf(8.0f * (float)u + 1.0f) - 1.0f) * 0.5f);
+        while (sy * (sy + 1) / 2 > u) --sy;
+        while ((sy + 1) * (sy + 2) / 2 <= u) ++sy;
+        sx = u - sy * (sy + 1) / 2;
+        if (sy >= sY) return;
+    } else {
+        if (u >= sY * sX) return;
+        sy = u / sX; sx = u - sy * sX;
+    }
+    // (triangular k ranges grow with m0 (kmode 2) or n0 (kmode 4): the long tiles first, the short ones fill the tail)
+    if (g.kmode == 2) sy = sY - 1 - sy;
+    if (g.kmode == 4) sx = sX - 1 - sx;
+    by = 8 * sy + (w >> 3); bx = 8 * sx + (w & 7);
+    if (by >= tY || bx >= tX) return;
+    }
+    const int m0 = by * GT, n0 = bx * GT;
     if (g.lower_only && m0 + GT - 1 < n0) return;
-    const double* A = g.A + (long)blockIdx.z * g.batchA;
-    const double* B = g.B + (long)blockIdx.z * g.batchB;
-    double* C = g.C + (long)blockIdx.z * g.batchC;
+    const int zi = g.zinner > 0 ? (int)blockIdx.z % g.zinner : (int)blockIdx.z, zo = g.zinner > 0 ? (int)blockIdx.z / g.zinner : 0;
+    const double* A = g.A + (long)zi * g.batchA + (long)zo * g.batchA2;
+    const double* B = g.B + (long)zi * g.batchB + (long)zo * g.batchB2;
+    double* C = g.C + (long)zi * g.batchC + (long)zo * g.batchC2;
     int kbeg = 0, kend = g.K;
     if (g.kmode == 1) kbeg = (max(m0, n0) / GK) * GK;
     else if (g.kmode == 2) kend = min(g.K, m0 + GT);
     else if (g.kmode == 3) kbeg = (n0 / GK) * GK;
+    else if (g.kmode == 4) kend = min(g.K, n0 + GT);
     d4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -381,7 +419,10 @@ __device__ __forceinline__ void dg_tile_gemm(int K, FA a, FB b, double (&c)[2][2
 #define DG_STAMP(i) do {} while (0)
 #define DG_STAMP_PRINT() do {} while (0)
 #endif
-__global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int n, double* Linv /* [128][128] */, int* status, int block_row0) {
+// grid.x = components of a batch: matrix, inverse block and status word of component z at z * bsA / bsL / bsS
+__global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int n, double* Linv /* [128][128] */, int* status, int block_row0,
+                                                       long bsA, long bsL, int bsS) {
+    A += (long)blockIdx.x * bsA; Linv += (long)blockIdx.x * bsL; status += (long)blockIdx.x * bsS;
 #ifdef MAGI_DIAG_STAMPS
     unsigned long long dg_st[16] = {0};
 #endif
@@ -567,8 +608,9 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
 }
 
 // helpers --------------------------------------------------------------------------------------
-__global__ void k_mirror_lower(double* A, int N) {           // A[j][i] = A[i][j] for j > i (tile transpose)
+__global__ void k_mirror_lower(double* A, int N, long bsA) {           // A[j][i] = A[i][j] for j > i (tile transpose); grid.z = batch
     __shared__ double t[32][33];
+    A += (long)blockIdx.z * bsA;
     const int bi = blockIdx.y, bj = blockIdx.x;
     if (bj > bi) return;
     const int i = bi * 32 + threadIdx.y, j = bj * 32 + threadIdx.x;
@@ -576,6 +618,17 @@ __global__ void k_mirror_lower(double* A, int N) {           // A[j][i] = A[i][j
     __syncthreads();
     const int oi = bj * 32 + threadIdx.y, oj = bi * 32 + threadIdx.x;   // transposed tile position
     if (oi < N && oj < N && oj > oi) A[(size_t)oi * N + oj] = t[threadIdx.x][threadIdx.y];
+}
+
+// the stored inverses of the diagonal blocks -> the diagonal of the triangular inverse; grid (blocks, batch)
+__global__ __launch_bounds__(256) void k_place_dinv(double* A, int N, const double* dinv, long bsA, long bsL) {
+    const int jb = blockIdx.x, j0 = jb * 128, n = min(128, N - j0);
+    double* dst = A + (long)blockIdx.y * bsA + (long)j0 * N + j0;
+    const double* src = dinv + (long)blockIdx.y * bsL + (long)jb * 128 * 128;
+    for (int e = threadIdx.x; e < 128 * 128; e += 256) {
+        const int i = e >> 7, j = e & 127;
+        if (i < n && j < n) dst[(long)i * N + j] = src[e];
+    }
 }
 
 __global__ void k_symmetrize(double* A, int N) {             // A = (A + A^T)/2, written to the lower part
@@ -717,9 +770,12 @@ struct Linalg {
     magi_handle* h;
     hipStream_t s;
     int N;
-    double* dinv = nullptr;     // [nb][128*128]
-    double* panel = nullptr;    // [N][128]
-    int* status = nullptr;
+    int batch = 1;              // components factorised together: every launch carries them on a grid axis
+    long bsA = 0;               // element stride between the components' matrices (potrf / trtri / lauum operate in place on A + z bsA)
+    double* dinv = nullptr;     // [batch][nb][128*128]
+    double* panel = nullptr;    // [batch][panel_elems]
+    long bs_dinv = 0, bs_panel = 0;
+    int* status = nullptr;      // [batch][2]
 };
 
 // optional per-class timing of the build (MAGI_BUILD_PROFILE=1): HIP events around every launch, so the
@@ -748,140 +804,172 @@ double gemm_flops(const GemmArgs& g, int batch) {
             if (g.kmode == 1) kb = (std::max(m0, n0) / GK) * GK;
             else if (g.kmode == 2) ke = std::min(g.K, m0 + GT);
             else if (g.kmode == 3) kb = (n0 / GK) * GK;
+            else if (g.kmode == 4) ke = std::min(g.K, n0 + GT);
             f += 2.0 * std::min(GT, g.M - m0) * std::min(GT, g.N - n0) * std::max(0, ke - kb);
         }
     return f * batch;
 }
 
-int launch_gemm(magi_handle* h, hipStream_t s, const GemmArgs& g, int batch = 1, int cls = BC_PROD) {
-    if (g.M <= 0 || g.N <= 0) return MAGI_OK;
-    dim3 grid((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, batch);
+int launch_gemm(magi_handle* h, hipStream_t s, const GemmArgs& g_in, int batch = 1, int cls = BC_PROD) {
+    GemmArgs g = g_in;
+    if (g.M <= 0 || g.N <= 0 || batch <= 0) return MAGI_OK;
+    const int tY = (g.M + GT - 1) / GT, tX = (g.N + GT - 1) / GT, sY = (tY + 7) / 8, sX = (tX + 7) / 8;
+    const int nsuper = g.lower_only ? sY * (sY + 1) / 2 : sY * sX;           // (lower-only: square tile grids)
+    static const int remap_min = [] { const char* e = getenv("MAGI_GEMM_REMAP_MIN"); return e ? atoi(e) : 24; }();
+    g.remap = (nsuper >= remap_min && (!g.lower_only || tY == tX)) ? 1 : 0;
+    dim3 grid(g.remap ? ((nsuper + 7) / 8) * 8 * 64 : tY * tX, 1, batch);
     prof_begin(s);
-    hipLaunchKernelGGL(k_gemm_f64, grid, dim3(256), 0, s, g);
+    switch (cls) {
+    case BC_PANEL: hipLaunchKernelGGL(k_gemm_f64<BC_PANEL>, grid, dim3(256), 0, s, g); break;
+    case BC_TRAIL: hipLaunchKernelGGL(k_gemm_f64<BC_TRAIL>, grid, dim3(256), 0, s, g); break;
+    case BC_TRTRI: hipLaunchKernelGGL(k_gemm_f64<BC_TRTRI>, grid, dim3(256), 0, s, g); break;
+    case BC_LAUUM: hipLaunchKernelGGL(k_gemm_f64<BC_LAUUM>, grid, dim3(256), 0, s, g); break;
+    case BC_FUSED: hipLaunchKernelGGL(k_gemm_f64<BC_FUSED>, grid, dim3(256), 0, s, g); break;
+    default: hipLaunchKernelGGL(k_gemm_f64<BC_PROD>, grid, dim3(256), 0, s, g); break;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("gemm launch: ") + hipGetErrorString(e));
     if (g_prof.on) prof_end(s, cls, gemm_flops(g, batch));
     return MAGI_OK;
 }
 
-// In-place lower Cholesky of A (N x N row-major, ld = N), right-looking, NB = 128.  The inverses
-// of the diagonal blocks are kept in la.dinv for the triangular inverse that follows.
-int potrf_status(Linalg& la, const char* what) {
+// In-place lower Cholesky of the la.batch matrices A + z la.bsA (N x N row-major, ld = N), all of them in every launch.
+// Right-looking over block columns of 256 = two 128-wide panels: the 128 x 128 diagonal blocks are factorised AND inverted by
+// k_diag_chol_inv (one workgroup per component), a panel is solved as a GEMM with that inverse, the second panel of a pair
+// takes the first one's rank-128 update on its own, and the trailing matrix takes BOTH panels in one rank-256 SYRK update on
+// the matrix cores -- twice the flops per byte of the trailing matrix's read-modify-write of a rank-128 sweep.
+// The inverses of the diagonal blocks stay in la.dinv for the triangular inverse that follows.
+int potrf_status(Linalg& la, const char* what, int status_slot = 0) {
     magi_handle* h = la.h;
-    int st = -1;
-    MAGI_HIP_CHECK(h, hipMemcpyAsync(&st, la.status, sizeof(int), hipMemcpyDeviceToHost, la.s));
+    std::vector<int> st((size_t)2 * la.batch, -1);
+    MAGI_HIP_CHECK(h, hipMemcpyAsync(st.data(), la.status, sizeof(int) * 2 * la.batch, hipMemcpyDeviceToHost, la.s));
     MAGI_HIP_CHECK(h, hipStreamSynchronize(la.s));
-    if (st >= 0)
-        return magi_fail(h, MAGI_E_NOTSPD, std::string("Cholesky of ") + what + ": non-positive pivot at index " + std::to_string(st));
+    for (int z = 0; z < la.batch; ++z)
+        if (st[(size_t)2 * z + status_slot] >= 0)
+            return magi_fail(h, MAGI_E_NOTSPD, std::string("Cholesky of ") + what + ": non-positive pivot at index " + std::to_string(st[(size_t)2 * z + status_slot]));
     return MAGI_OK;
 }
 
 // defer_status: only enqueue (no host synchronisation); the caller asks potrf_status later
-// status_slot: which of the two status words of `la` records a failed pivot (a deferred caller may have two factorisations
-// in flight on the stream)
+// status_slot: which of the two status words per component records a failed pivot (a deferred caller may have two
+// factorisations in flight on the stream)
 int potrf(Linalg& la, double* A, const char* what, bool defer_status = false, int status_slot = 0) {
     magi_handle* h = la.h;
     const int N = la.N, NB = 128;
-    int* status = la.status + status_slot;
-    MAGI_HIP_CHECK(h, hipMemsetAsync(status, 0xFF, sizeof(int), la.s));          // -1
     const size_t lds = (size_t)DG_LDS_DOUBLES * sizeof(double);
-    for (int j0 = 0, jb = 0; j0 < N; j0 += NB, ++jb) {
-        const int n = std::min(NB, N - j0);
-        double* Ajj = A + (size_t)j0 * N + j0;
+    for (int z = 0; z < la.batch; ++z)          // status words of this slot <- -1
+        MAGI_HIP_CHECK(h, hipMemsetAsync(la.status + 2 * z + status_slot, 0xFF, sizeof(int), la.s));
+    auto diag = [&](int j0, int n) {
         prof_begin(la.s);
-        hipLaunchKernelGGL(k_diag_chol_inv, dim3(1), dim3(256), lds, la.s, Ajj, (long)N, n, la.dinv + (size_t)jb * 128 * 128, status, j0);
-        prof_end(la.s, BC_DIAG, (double)n * n * n);        // n^3/3 factor + 2 n^3/3 inverse
-        const int M = N - j0 - n;
-        if (M <= 0) break;
-        double* P = A + (size_t)(j0 + n) * N + j0;       // panel below the diagonal block
+        hipLaunchKernelGGL(k_diag_chol_inv, dim3(la.batch), dim3(256), lds, la.s, A + (size_t)j0 * N + j0, (long)N, n,
+                           la.dinv + (size_t)(j0 / NB) * 128 * 128, la.status + status_slot, j0, la.bsA, la.bs_dinv, 2);
+        prof_end(la.s, BC_DIAG, (double)n * n * n * la.batch);        // n^3/3 factor + 2 n^3/3 inverse
+    };
+    auto panel = [&](int j0, int n, int row0) -> int {               // rows >= row0 of block column j0 <- . Linv_jj^T
         GemmArgs g{};
-        // P <- P * Linv_jj^T   (n == 128 here because a panel exists)
+        double* P = A + (size_t)row0 * N + j0;
         g.A = P; g.sAm = N; g.sAk = 1;
-        g.B = la.dinv + (size_t)jb * 128 * 128; g.sBn = 128; g.sBk = 1;
-        g.C = P; g.ldc = N; g.M = M; g.N = n; g.K = n; g.alpha = 1.0; g.beta = 0.0;
-        int rc = launch_gemm(h, la.s, g, 1, BC_PANEL);
-        if (rc) return rc;
-        // trailing (lower tiles): A22 <- A22 - P P^T
+        g.B = la.dinv + (size_t)(j0 / NB) * 128 * 128; g.sBn = 128; g.sBk = 1;
+        g.C = P; g.ldc = N; g.M = N - row0; g.N = n; g.K = n; g.alpha = 1.0; g.beta = 0.0;
+        g.batchA = la.bsA; g.batchB = la.bs_dinv; g.batchC = la.bsA;
+        return launch_gemm(h, la.s, g, la.batch, BC_PANEL);
+    };
+    auto syrk = [&](int row0, int ncols, int k0, int K) -> int {     // A[row0.., row0 .. row0 + ncols) -= A[row0.., k0 .. k0+K) A[row0 .. row0+ncols, k0 .. k0+K)^T (lower tiles)
         GemmArgs t{};
+        double* P = A + (size_t)row0 * N + k0;
         t.A = P; t.sAm = N; t.sAk = 1;
         t.B = P; t.sBn = N; t.sBk = 1;
-        t.C = A + (size_t)(j0 + n) * N + (j0 + n); t.ldc = N; t.M = M; t.N = M; t.K = n; t.alpha = -1.0; t.beta = 1.0;
-        t.lower_only = 1;
-        if ((rc = launch_gemm(h, la.s, t, 1, BC_TRAIL))) return rc;
+        t.C = A + (size_t)row0 * N + row0; t.ldc = N; t.M = N - row0; t.N = ncols; t.K = K; t.alpha = -1.0; t.beta = 1.0;
+        t.lower_only = ncols > GT ? 1 : 0;          // (a single tile column has no tile above the diagonal)
+        t.batchA = la.bsA; t.batchB = la.bsA; t.batchC = la.bsA;
+        return launch_gemm(h, la.s, t, la.batch, BC_TRAIL);
+    };
+    int rc = MAGI_OK;
+    for (int j0 = 0; j0 < N && rc == MAGI_OK; j0 += 2 * NB) {
+        const int n1 = std::min(NB, N - j0);
+        diag(j0, n1);
+        const int j1 = j0 + NB;
+        if (j1 >= N) break;
+        if ((rc = panel(j0, n1, j1))) break;
+        const int n2 = std::min(NB, N - j1);
+        if ((rc = syrk(j1, n2, j0, NB))) break;                        // second panel of the pair: rank-128 update from the first
+        diag(j1, n2);
+        const int j2 = j1 + NB;
+        if (j2 >= N) break;
+        if ((rc = panel(j1, n2, j2))) break;
+        rc = syrk(j2, N - j2, j0, 2 * NB);                             // trailing matrix: both panels, rank 256
     }
-    return defer_status ? MAGI_OK : potrf_status(la, what);
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("potrf launch: ") + hipGetErrorString(e));
+    return defer_status ? MAGI_OK : potrf_status(la, what, status_slot);
 }
 
-// In-place T = L^-1 (lower) from the factor left by potrf, bottom-up over block sizes s = 128, 256, ...:
-//   [T11 0; T21 T22] with T21 = -T22 (L21 T11).  Every level is two batched MFMA GEMMs over all block
-//   pairs, so the large levels expose (s/128)^2 x pairs tiles instead of the N/128 of a column sweep
+// In-place T = L^-1 (lower) from the factors left by potrf, bottom-up over block sizes s = 128, 256, ...:
+//   [T11 0; T21 T22] with T21 = -T22 (L21 T11).  Every level is two batched MFMA GEMMs over all block pairs of all
+//   components, so the large levels expose (s/128)^2 x pairs tiles instead of the N/128 of a column sweep
 //   (measured at N=8192: 429 ms -> see profiles/).  The diagonal 128-blocks come from k_diag_chol_inv.
 int trtri(Linalg& la, double* A) {
     magi_handle* h = la.h;
     const int N = la.N, NB = 128;
     const int nb = (N + NB - 1) / NB;
-    for (int jb = 0; jb < nb; ++jb) {
-        const int j0 = jb * NB, n = std::min(NB, N - j0);
-        MAGI_HIP_CHECK(h, hipMemcpy2DAsync(A + (size_t)j0 * N + j0, (size_t)N * sizeof(double), la.dinv + (size_t)jb * 128 * 128,
-                                           128 * sizeof(double), (size_t)n * sizeof(double), n, hipMemcpyDeviceToDevice, la.s));
-    }
+    hipLaunchKernelGGL(k_place_dinv, dim3(nb, la.batch), dim3(256), 0, la.s, A, N, la.dinv, la.bsA, la.bs_dinv);
     for (long s = NB; s < N; s *= 2) {
         const int nfull = (int)(N / (2 * s));
         const long rem = N - (long)nfull * 2 * s;            // rows left after the full pairs
         for (int pass = 0; pass < 2; ++pass) {
-            int batch; long b0; int M2;
-            if (pass == 0) { batch = nfull; b0 = 0; M2 = (int)s; }
-            else { batch = (rem > s) ? 1 : 0; b0 = (long)nfull * 2 * s; M2 = (int)(rem - s); }
-            if (batch <= 0) continue;
+            int pairs; long b0; int M2;
+            if (pass == 0) { pairs = nfull; b0 = 0; M2 = (int)s; }
+            else { pairs = (rem > s) ? 1 : 0; b0 = (long)nfull * 2 * s; M2 = (int)(rem - s); }
+            if (pairs <= 0) continue;
             const long pstride = 2 * s * ((long)N + 1);
             double* base = A + b0 * ((long)N + 1);
             GemmArgs g{};   // tmp <- L21 T11                 (T11 lower: B(n,k) = T11[k][n] = 0 for k < n)
             g.A = base + s * N; g.sAm = N; g.sAk = 1;
             g.B = base; g.sBn = 1; g.sBk = N;
             g.C = la.panel; g.ldc = s; g.M = M2; g.N = (int)s; g.K = (int)s; g.alpha = 1.0; g.beta = 0.0; g.kmode = 3;
+            g.zinner = pairs;
             g.batchA = pstride; g.batchB = pstride; g.batchC = s * s;
-            int rc = launch_gemm(h, la.s, g, batch, BC_TRTRI);
+            g.batchA2 = la.bsA; g.batchB2 = la.bsA; g.batchC2 = la.bs_panel;
+            int rc = launch_gemm(h, la.s, g, pairs * la.batch, BC_TRTRI);
             if (rc) return rc;
             GemmArgs t{};   // T21 <- -T22 tmp                 (T22 lower: k < m0 + 128)
             t.A = base + s * N + s; t.sAm = N; t.sAk = 1;
             t.B = la.panel; t.sBn = 1; t.sBk = s;
             t.C = base + s * N; t.ldc = N; t.M = M2; t.N = (int)s; t.K = M2; t.alpha = -1.0; t.beta = 0.0; t.kmode = 2;
+            t.zinner = pairs;
             t.batchA = pstride; t.batchB = s * s; t.batchC = pstride;
-            if ((rc = launch_gemm(h, la.s, t, batch, BC_TRTRI))) return rc;
+            t.batchA2 = la.bsA; t.batchB2 = la.bs_panel; t.batchC2 = la.bsA;
+            if ((rc = launch_gemm(h, la.s, t, pairs * la.batch, BC_TRTRI))) return rc;
         }
     }
     return MAGI_OK;
 }
 
-// out = T^T T (full symmetric), T lower in A
-int lauum_tt(Linalg& la, const double* T, double* out) {
+// out + z bs_out = T^T T (full symmetric), T lower in A + z la.bsA
+int lauum_tt(Linalg& la, const double* T, double* out, long bs_out) {
     GemmArgs g{};
     const int N = la.N;
     g.A = T; g.sAm = 1; g.sAk = N;      // A(m,k) = T[k][m]
     g.B = T; g.sBn = 1; g.sBk = N;      // B(n,k) = T[k][n]
     g.C = out; g.ldc = N; g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 0.0;
     g.lower_only = 1; g.kmode = 1;
-    int rc = launch_gemm(la.h, la.s, g, 1, BC_LAUUM);
+    g.batchA = la.bsA; g.batchB = la.bsA; g.batchC = bs_out;
+    int rc = launch_gemm(la.h, la.s, g, la.batch, BC_LAUUM);
     if (rc) return rc;
-    dim3 grid((N + 31) / 32, (N + 31) / 32);
-    hipLaunchKernelGGL(k_mirror_lower, grid, dim3(32, 32), 0, la.s, out, N);
+    dim3 grid((N + 31) / 32, (N + 31) / 32, la.batch);
+    hipLaunchKernelGGL(k_mirror_lower, grid, dim3(32, 32), 0, la.s, out, N, bs_out);
     return MAGI_OK;
 }
 
-// A (SPD, overwritten) -> out = A^-1
-int spd_inverse(Linalg& la, double* A, double* out, const char* what, bool defer_status = false, int status_slot = 0) {
-    int rc = potrf(la, A, what, defer_status, status_slot);
-    if (rc) return rc;
-    if ((rc = trtri(la, A))) return rc;
-    return lauum_tt(la, A, out);
-}
-
-int linalg_init(Linalg& la, magi_handle* h, int N) {
-    la.h = h; la.s = h->stream; la.N = N;
+int linalg_init(Linalg& la, magi_handle* h, int N, int batch = 1, long bsA = 0) {
+    la.h = h; la.s = h->stream; la.N = N; la.batch = batch; la.bsA = bsA;
     const int nb = (N + 127) / 128;
-    MAGI_HIP_CHECK(h, hipMalloc(&la.dinv, (size_t)nb * 128 * 128 * sizeof(double)));
-    MAGI_HIP_CHECK(h, hipMalloc(&la.panel, std::max((size_t)N * 128, (size_t)N * N / 2 + 128 * 128) * sizeof(double)));
-    MAGI_HIP_CHECK(h, hipMalloc(&la.status, 2 * sizeof(int)));
+    la.bs_dinv = (long)nb * 128 * 128;
+    la.bs_panel = (long)std::max((size_t)N * 128, (size_t)N * N / 2 + 128 * 128);
+    MAGI_HIP_CHECK(h, hipMalloc(&la.dinv, (size_t)la.bs_dinv * batch * sizeof(double)));
+    MAGI_HIP_CHECK(h, hipMalloc(&la.panel, (size_t)la.bs_panel * batch * sizeof(double)));
+    MAGI_HIP_CHECK(h, hipMalloc(&la.status, (size_t)2 * batch * sizeof(int)));
     MAGI_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_diag_chol_inv), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS_DOUBLES * (int)sizeof(double)));
     return MAGI_OK;
 }
@@ -972,7 +1060,7 @@ int fit_issue(magi_handle* h, FitWork& w, double phi1, double phi2, double sig2,
         hipLaunchKernelGGL(k_fit_logdiag, dim3(1), dim3(256), 0, h->stream, w.S.p, N, w.out.p + 5);
         rc = trtri(w.la, w.S.p);
     }
-    if (rc == MAGI_OK) rc = lauum_tt(w.la, w.S.p, w.Sinv.p);
+    if (rc == MAGI_OK) rc = lauum_tt(w.la, w.S.p, w.Sinv.p, 0);
     if (rc == MAGI_OK) {
         hipLaunchKernelGGL(k_fit_gemv, dim3((N + 3) / 4), dim3(256), 0, h->stream, w.Sinv.p, w.r.p, w.alpha.p, N);
         hipLaunchKernelGGL(k_fit_terms, dim3(w.nblk), dim3(256), 0, h->stream, w.Kap.p, w.pK.p, w.Sinv.p, w.alpha.p, w.r.p, w.I.p, N, w.part.p);
@@ -1206,93 +1294,90 @@ int magi_build_matrices_device(magi_handle* h, const double* I, int N, int D, co
     for (int d = 0; d < D; ++d)
         if (!(phi1[d] > 0.0) || !(phi2[d] > 0.0)) return magi_fail(h, MAGI_E_BADARG, "phi1 and phi2 must be positive");
     const size_t nn = (size_t)N * N;
-    // The D components are independent: each gets a stream and a work space (Kappa, p_Kappa, Kappa_pp, Cholesky scratch), so
-    // the one-workgroup diagonal-block kernels and the thin panels of one component run under the GEMMs of the others and
-    // small grids (64 tiles per GEMM at N = 1024) fill the GPU together.  W < D work spaces when memory is short: component
-    // d then follows component d - W on the same stream.
+    // The D components are independent and go through the SAME sequence of launches, so they are batched: every kernel of the
+    // chain carries all components of a group on a grid axis (one stream, D times fewer launches, D times the tiles per launch:
+    // the one-workgroup diagonal-block kernels of the components run side by side and the thin panels fill the GPU together).
+    // B < D components per group when memory is short (or MAGI_BUILD_SERIAL is set): the groups follow each other.
     DevBuf dI, dCinv, dM, dKinv;
     MAGI_HIP_CHECK(h, dI.alloc(N));
     MAGI_HIP_CHECK(h, dCinv.alloc(nn * D));
     MAGI_HIP_CHECK(h, dM.alloc(nn * D));
     MAGI_HIP_CHECK(h, dKinv.alloc(nn * D));
     MAGI_HIP_CHECK(h, hipMemcpy(dI.p, I, sizeof(double) * N, hipMemcpyHostToDevice));
-    MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    struct Work { DevBuf Kap, P, PP; Linalg la{}; hipStream_t stream = nullptr; };
-    int W = D;
+    int B = D;
     {
         size_t free_b = 0, total_b = 0;
         const size_t per = (3 * nn + std::max((size_t)N * 128, nn / 2 + 128 * 128) + (size_t)((N + 127) / 128) * 128 * 128) * sizeof(double);
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            W = (int)std::max<size_t>(1, std::min<size_t>((size_t)D, (free_b / 10 * 9) / per));
-        if (g_prof.on || getenv("MAGI_BUILD_SERIAL")) W = 1;
+            B = (int)std::max<size_t>(1, std::min<size_t>((size_t)D, (free_b / 10 * 9) / per));
+        if (getenv("MAGI_BUILD_SERIAL")) B = 1;
     }
-    std::vector<Work> ws(W);
-    int rc = MAGI_OK;
-    auto cleanup = [&]() {
-        for (auto& w : ws) { linalg_free(w.la); if (w.stream) (void)hipStreamDestroy(w.stream); }
-    };
-    for (int k = 0; k < W && rc == MAGI_OK; ++k) {
-        Work& w = ws[k];
-        hipError_t e = w.Kap.alloc(nn);
-        if (e == hipSuccess) e = w.P.alloc(nn);
-        if (e == hipSuccess) e = w.PP.alloc(nn);
-        if (e == hipSuccess) e = hipStreamCreate(&w.stream);
-        if (e != hipSuccess) { rc = magi_fail(h, MAGI_E_HIP, std::string("build setup: ") + hipGetErrorString(e)); break; }
-        rc = linalg_init(w.la, h, N);
-        w.la.s = w.stream;
-    }
-    if (rc) { cleanup(); return rc; }
-    int* status = nullptr;                          // pinned, so the read-backs below do not stall the host between components
-    if (hipHostMalloc(reinterpret_cast<void**>(&status), (size_t)2 * D * sizeof(int)) != hipSuccess) { cleanup(); return magi_fail(h, MAGI_E_HIP, "build: pinned status"); }
-    for (int k = 0; k < 2 * D; ++k) status[k] = -1;
-    hipStream_t keep = h->stream;
-    for (int d = 0; d < D && rc == MAGI_OK; ++d) {
-        Work& w = ws[d % W];
-        h->stream = w.stream;                       // launch_matern and the element-wise helpers launch on the handle's stream
-        double* Cd = dCinv.p + nn * d;
-        double* Md = dM.p + nn * d;
-        double* Kd = dKinv.p + nn * d;
-        rc = launch_matern(h, dI.p, N, phi1[d], phi2[d], nu, w.Kap.p, w.P.p, w.PP.p);
-        // C^-1 = Kappa^-1 (Kappa is consumed)                              magi_v2.py:818, 126
-        if (!rc) rc = spd_inverse(w.la, w.Kap.p, Cd, "Kappa", true, 0);
-        // m = p_Kappa Kappa^-1                                              magi_v2.py:819
+    DevBuf Kap, P, PP;
+    MAGI_HIP_CHECK(h, Kap.alloc(nn * B));
+    MAGI_HIP_CHECK(h, P.alloc(nn * B));
+    MAGI_HIP_CHECK(h, PP.alloc(nn * B));
+    Linalg la{};
+    int rc = linalg_init(la, h, N, B, (long)nn);
+    std::vector<int> status((size_t)2 * D, -1);
+    for (int d0 = 0; d0 < D && rc == MAGI_OK; d0 += B) {
+        const int nb = std::min(B, D - d0);
+        la.batch = nb;
+        for (int z = 0; z < nb && rc == MAGI_OK; ++z)
+            rc = launch_matern(h, dI.p, N, phi1[d0 + z], phi2[d0 + z], nu, Kap.p + nn * z, P.p + nn * z, PP.p + nn * z);
+        double* Cd = dCinv.p + nn * d0;
+        double* Md = dM.p + nn * d0;
+        double* Kd = dKinv.p + nn * d0;
+        // Kappa = L L^T, T = L^-1, C^-1 = Kappa^-1 = T^T T   (Kappa is consumed)            magi_v2.py:818, 126
+        if (!rc) rc = potrf(la, Kap.p, "Kappa", true, 0);
+        if (!rc) rc = trtri(la, Kap.p);
+        if (!rc) rc = lauum_tt(la, Kap.p, Cd, (long)nn);
+        // Wt = (p_Kappa T^T)^T = T p_Kappa^T = -T p_Kappa   (p_Kappa is exactly antisymmetric: the sign of s - t is its only odd
+        // factor, magi_v2.py:798-802).  T lower: k < m0 + 128.  Kept in the K^-1 output buffer until that is formed.  Formed as the
+        // TRANSPOSE of W so that the two products below read both operands along their unit-stride dimension (A m-fast,
+        // B n-fast): the k-fast x k-fast forms of W T and W W^T ran at 0.55 of the MFMA peak.
         if (!rc) {
             GemmArgs g{};
-            g.A = w.P.p; g.sAm = N; g.sAk = 1;
-            g.B = Cd; g.sBn = 1; g.sBk = N;
-            g.C = Md; g.ldc = N; g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 0.0;
-            rc = launch_gemm(h, w.stream, g);
+            g.A = Kap.p; g.sAm = N; g.sAk = 1;
+            g.B = P.p; g.sBn = 1; g.sBk = N;
+            g.C = Kd; g.ldc = N; g.M = N; g.N = N; g.K = N; g.alpha = -1.0; g.beta = 0.0; g.kmode = 2;
+            g.batchA = (long)nn; g.batchB = (long)nn; g.batchC = (long)nn;
+            rc = launch_gemm(h, la.s, g, nb);
         }
-        // K = Kappa_pp - m Kappa_p = Kappa_pp + m p_Kappa  (Kappa_p = -p_Kappa, :805, :820)
+        // m = p_Kappa Kappa^-1 = W T = Wt^T T  (B(n,k) = T[k][n] = 0 for k < n)              magi_v2.py:819
         if (!rc) {
             GemmArgs g{};
-            g.A = Md; g.sAm = N; g.sAk = 1;
-            g.B = w.P.p; g.sBn = 1; g.sBk = N;
-            g.C = w.PP.p; g.ldc = N; g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 1.0;
-            rc = launch_gemm(h, w.stream, g);
+            g.A = Kd; g.sAm = 1; g.sAk = N;
+            g.B = Kap.p; g.sBn = 1; g.sBk = N;
+            g.C = Md; g.ldc = N; g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 0.0; g.kmode = 3;
+            g.batchA = (long)nn; g.batchB = (long)nn; g.batchC = (long)nn;
+            rc = launch_gemm(h, la.s, g, nb);
         }
+        // K = Kappa_pp - p_Kappa Kappa^-1 Kappa_p = Kappa_pp - W W^T = Kappa_pp - Wt^T Wt  (Kappa_p = -p_Kappa = p_Kappa^T,
+        // magi_v2.py:805, 820): a SYRK on the lower tiles -- exactly symmetric by construction; its Cholesky reads the lower
+        // triangle only
         if (!rc) {
-            dim3 grid((N + 31) / 32, (N + 31) / 32);
-            hipLaunchKernelGGL(k_symmetrize, grid, dim3(32, 32), 0, w.stream, w.PP.p, N);
-            rc = spd_inverse(w.la, w.PP.p, Kd, "K_d", true, 1);              // magi_v2.py:128
+            GemmArgs g{};
+            g.A = Kd; g.sAm = 1; g.sAk = N;
+            g.B = Kd; g.sBn = 1; g.sBk = N;
+            g.C = PP.p; g.ldc = N; g.M = N; g.N = N; g.K = N; g.alpha = -1.0; g.beta = 1.0; g.lower_only = 1;
+            g.batchA = (long)nn; g.batchB = (long)nn; g.batchC = (long)nn;
+            rc = launch_gemm(h, la.s, g, nb);
         }
-        // the two pivot words of this component, read back in stream order before the work space is reused
-        if (!rc && hipMemcpyAsync(&status[(size_t)2 * d], w.la.status, 2 * sizeof(int), hipMemcpyDeviceToHost, w.stream) != hipSuccess)
+        // K^-1                                                                                magi_v2.py:128
+        if (!rc) rc = potrf(la, PP.p, "K_d", true, 1);
+        if (!rc) rc = trtri(la, PP.p);
+        if (!rc) rc = lauum_tt(la, PP.p, Kd, (long)nn);
+        if (!rc && hipMemcpyAsync(&status[(size_t)2 * d0], la.status, (size_t)2 * nb * sizeof(int), hipMemcpyDeviceToHost, la.s) != hipSuccess)
             rc = magi_fail(h, MAGI_E_HIP, "build: status readback");
+        if (!rc && hipStreamSynchronize(la.s) != hipSuccess) rc = magi_fail(h, MAGI_E_HIP, "build: synchronize");
     }
-    h->stream = keep;
-    hipError_t se = hipSuccess;
-    for (auto& w : ws) { hipError_t e = hipStreamSynchronize(w.stream); if (se == hipSuccess) se = e; }
-    cleanup();
-    std::vector<int> st(status, status + 2 * D);
-    (void)hipHostFree(status);
+    linalg_free(la);
     if (rc) return rc;
-    if (se != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("build: ") + hipGetErrorString(se));
     for (int d = 0; d < D; ++d)
         for (int k = 0; k < 2; ++k)
-            if (st[(size_t)2 * d + k] >= 0)
+            if (status[(size_t)2 * d + k] >= 0)
                 return magi_fail(h, MAGI_E_NOTSPD, std::string("Cholesky of ") + (k ? "K_d" : "Kappa") + " (component " + std::to_string(d) +
-                                 "): non-positive pivot at index " + std::to_string(st[(size_t)2 * d + k]));
+                                 "): non-positive pivot at index " + std::to_string(status[(size_t)2 * d + k]));
     if (C_inv) MAGI_HIP_CHECK(h, hipMemcpy(C_inv, dCinv.p, nn * D * sizeof(double), hipMemcpyDeviceToHost));
     if (m) MAGI_HIP_CHECK(h, hipMemcpy(m, dM.p, nn * D * sizeof(double), hipMemcpyDeviceToHost));
     if (K_inv) MAGI_HIP_CHECK(h, hipMemcpy(K_inv, dKinv.p, nn * D * sizeof(double), hipMemcpyDeviceToHost));

@@ -38,6 +38,36 @@ void run(const double2* p, double* out, int nblk, const char* name) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%-28s depth %2d: %7.2f us  %5.2f TB/s\n", name, DEPTH, ms * 1e3 / reps, nblk * 131072.0 / (ms * 1e-3 / reps) / 1e12);
 }
+// alternating direction: does an XCD's L2 keep the tail of one launch for the head of the next?  (544 blocks = 9 MB per XCD, L2 = 4 MB)
+template <int DEPTH>
+__global__ __launch_bounds__(256) void k_read_dir(const double2* __restrict__ p, double* out, int rev) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const double2* q = p + (size_t)blockIdx.x * 8192;
+    auto addr = [&](int k) -> const double2* { const int kk = rev ? 31 - k : k; return q + (size_t)(32 * wave + kk) * 64 + lane; };
+    double2 r[DEPTH];
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) r[k] = *addr(k);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const double2 v = r[k % DEPTH];
+        a += v.x + v.y;
+        if (k + DEPTH < 32) r[k % DEPTH] = *addr(k + DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (a == 12345.678) out[0] = a;
+}
+template <int DEPTH>
+void run_dir(const double2* p, double* out, int nblk, int alternate) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int w = 0; w < 4; ++w) hipLaunchKernelGGL((k_read_dir<DEPTH>), dim3(nblk), dim3(256), 0, 0, p, out, alternate ? (w & 1) : 0);
+    (void)hipEventRecord(e0);
+    const int reps = 50;
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_read_dir<DEPTH>), dim3(nblk), dim3(256), 0, 0, p, out, alternate ? (r & 1) : 0);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("%-28s depth %2d: %7.2f us  %5.2f TB/s\n", alternate ? "alternating direction" : "same direction", DEPTH, ms * 1e3 / reps, nblk * 131072.0 / (ms * 1e-3 / reps) / 1e12);
+}
 int main() {
     const int nblk = 544;
     double2* p; double* out;
@@ -52,5 +82,8 @@ int main() {
     run<1, 12>(p, out, nblk, "4 rows x 256 B per instr");
     run<1, 8>(p, out, nblk, "4 rows x 256 B per instr");
     run<1, 4>(p, out, nblk, "4 rows x 256 B per instr");
+    run_dir<32>(p, out, nblk, 0); run_dir<32>(p, out, nblk, 1);
+    run_dir<8>(p, out, nblk, 0); run_dir<8>(p, out, nblk, 1);
+    run_dir<4>(p, out, nblk, 0); run_dir<4>(p, out, nblk, 1);
     return 0;
 }
