@@ -96,6 +96,25 @@ int magi_matern_blocks(magi_handle* h, const double* I, int N, double phi1, doub
 int magi_set_matrices(magi_handle* h, int N, int D, int bandsize,
                       const double* C_inv, const double* m, const double* K_inv);
 
+/* The three entry points above keep dense device copies of C^-1, m, K^-1 ([D][N][N], before the band mask) resident in the
+ * handle; the calls below let a caller stage its work on them without moving N x N matrices over PCIe
+ * (MAGI_v2.initial_fit builds the observed components, initialises theta against the UNbanded m / K^-1, builds the
+ * unobserved components later and only then applies the band: magi_v2.py:122-128, 133-179, 262-274).
+ *
+ * magi_build_dense: Eqn.-6 matrices of the components sel[0 .. n_sel) (phi1 / phi2 indexed like sel) into the resident
+ *   stacks of a D-component problem (stacks are allocated, and zero for components not built yet, when N or D change).
+ *   Invalidates the packed operands until magi_pack_resident.
+ * magi_pack_resident: band mask + packing of the resident stacks (what magi_build_matrices / magi_set_matrices do last).
+ * magi_get_dense: host copies of the resident stacks with tf.linalg.band_part(., b, b) applied (bandsize < 0: as built);
+ *   any pointer may be NULL.
+ * magi_dense_apply: Y[d] = A_d V[d] (transpose = 0) or A_d^T V[d] for the resident stack `which` (0 = C^-1, 1 = m,
+ *   2 = K^-1); V, Y host [D][N][nv], nv <= 8 -- the N x N products of the theta initialiser (magi_v2.py:142, 157-158). */
+int magi_build_dense(magi_handle* h, const double* I, int N, int D, int n_sel, const int32_t* sel,
+                     const double* phi1, const double* phi2, double nu);
+int magi_pack_resident(magi_handle* h, int bandsize);
+int magi_get_dense(magi_handle* h, int bandsize, double* C_inv, double* m, double* K_inv);
+int magi_dense_apply(magi_handle* h, int which, int transpose, int nv, const double* V, double* Y);
+
 /* ---- log posterior ------------------------------------------------------------------------ */
 
 /* Constants captured by the reference's log-posterior closure (magi_v2.py:294-300):

@@ -38,14 +38,11 @@ def _band(A: np.ndarray, b: Optional[int]) -> np.ndarray:
     return A * (np.abs(i[:, None] - i[None, :]) <= b)
 
 
-def _fingerprint(*arrays) -> tuple:
-    out = []
-    for a in arrays:
-        a = np.asarray(a)
-        flat = a.reshape(-1)
-        step = max(1, flat.shape[0] // 4096)
-        out.append((a.shape, float(flat[::step].sum()), float(flat[-1]), float(flat[0])))
-    return tuple(out)
+def _digest(a) -> bytes:
+    """Full-content hash of a host matrix stack (an in-place edit anywhere is seen)."""
+    import hashlib
+    a = np.ascontiguousarray(a)
+    return hashlib.blake2b(a.view(np.uint8).reshape(-1).data, digest_size=16).digest() + repr(a.shape).encode()
 
 
 class MAGI_v2:
@@ -79,13 +76,19 @@ class MAGI_v2:
         self.sigma_sqs_init = np.full((self.D,), np.nan)
         self.Xhat_init, self.thetas_init = None, None
         self.mu_ds = np.full((self.D,), np.nan)
-        self.C_d_invs, self.m_ds, self.K_d_invs = None, None, None
+        # C_d_invs / m_ds / K_d_invs (magi_v2.py:117-119): the authoritative copies live on the GPU; the attributes are
+        # properties that download on first read and upload again only if the caller assigned or edited them
+        self._host_mats = [None, None, None]
+        self._host_digests = [None, None, None]
+        self._assigned = [False, False, False]
+        self._dev_valid = False          # the handle's dense stacks hold the current matrices
+        self._band_applied = False       # magi_v2.py:271-274 has run (host copies are masked; the device masks when packing)
+        self._packed_for = None          # bandsize the device operands were last packed with
 
         self.f_vec = f_vec
         self.drift = _drift.resolve(f_vec, self.D, D_thetas)       # built-in, or traced + JIT-compiled (drift.py, jit.py)
         self._device = device
         self._engine: Optional[MagiEngine] = None
-        self._resident = None       # fingerprint of the matrices currently on the device
 
     # ------------------------------------------------------------------------------------------
     @property
@@ -94,25 +97,77 @@ class MAGI_v2:
             self._engine = MagiEngine(self._device, drift=self.drift)      # raises without libmagi_hip.so / GPU
         return self._engine
 
+    # -- matrices: device-resident, lazily mirrored on the host ----------------------------------------------------
+    def _materialise(self):
+        if self._dev_valid and any(m is None for m in self._host_mats):
+            got = self.engine.get_dense(self.BANDSIZE if self._band_applied else None)
+            for k in range(3):
+                if self._host_mats[k] is None:
+                    self._host_mats[k] = got[k]
+                    self._host_digests[k] = _digest(got[k])
+
+    def _get_mat(self, k):
+        self._materialise()
+        return self._host_mats[k]
+
+    def _set_mat(self, k, value):
+        self._host_mats[k] = value
+        self._assigned[k] = value is not None
+        self._host_digests[k] = None
+
+    C_d_invs = property(lambda self: self._get_mat(0), lambda self, v: self._set_mat(0, v))
+    m_ds = property(lambda self: self._get_mat(1), lambda self, v: self._set_mat(1, v))
+    K_d_invs = property(lambda self: self._get_mat(2), lambda self, v: self._set_mat(2, v))
+
+    def _host_overrides(self) -> bool:
+        """True when the caller assigned one of the three attributes or edited a downloaded copy in place."""
+        return any(self._assigned) or any(m is not None and d is not None and _digest(m) != d
+                                          for m, d in zip(self._host_mats, self._host_digests))
+
     def _build(self, comps: Sequence[int], phi1s, phi2s):
-        """Eqn. 6 matrices for the listed components on the GPU (magi_v2.py:122-128, 262-268, 447-451)."""
-        C_inv, m, K_inv = self.engine.build_matrices(self.I, phi1s, phi2s, 2.01, bandsize=None)
-        for k, d in enumerate(comps):
-            self.C_d_invs[d], self.m_ds[d], self.K_d_invs[d] = C_inv[k], m[k], K_inv[k]
+        """Eqn. 6 matrices for the listed components on the GPU (magi_v2.py:122-128, 262-268, 447-451): built into the
+        handle's dense stacks, no host copy."""
+        self.engine.build_dense(self.I, self.D, list(comps), phi1s, phi2s, 2.01)
+        self._dev_valid = True
+        self._host_mats, self._host_digests, self._assigned = [None] * 3, [None] * 3, [False] * 3
+        self._packed_for = None
 
     def _apply_band(self):
-        """magi_v2.py:271-274 / 459-462 (host copies; the device applies the same mask when loading)."""
+        """magi_v2.py:271-274 / 459-462: the device applies the mask when it packs; host copies that exist are masked here."""
+        self._band_applied = True
         if self.BANDSIZE is not None:
-            self.C_d_invs = _band(self.C_d_invs, self.BANDSIZE)
-            self.K_d_invs = _band(self.K_d_invs, self.BANDSIZE)
-            self.m_ds = _band(self.m_ds, self.BANDSIZE)
+            for k in range(3):
+                if self._host_mats[k] is not None:
+                    keep = self._assigned[k]
+                    self._host_mats[k] = _band(np.asarray(self._host_mats[k]), self.BANDSIZE)
+                    self._assigned[k] = keep
+                    if not keep:
+                        self._host_digests[k] = _digest(self._host_mats[k])
+        self._packed_for = None
 
     def _sync_matrices(self):
-        fp = _fingerprint(self.C_d_invs, self.m_ds, self.K_d_invs) + (self.BANDSIZE,)
-        if fp != self._resident:
-            self.engine.set_matrices(np.asarray(self.C_d_invs), np.asarray(self.m_ds), np.asarray(self.K_d_invs),
-                                     bandsize=self.BANDSIZE)
-            self._resident = fp
+        if self._host_overrides() or not self._dev_valid:
+            self._materialise()                    # (the ones the caller did not touch)
+            assert all(m is not None for m in self._host_mats), "C_d_invs, m_ds and K_d_invs must be set (run initial_fit first)."
+            mats = [np.asarray(m, dtype=np.float64) for m in self._host_mats]
+            self.engine.set_matrices(*mats, bandsize=self.BANDSIZE)
+            self._dev_valid = True
+            self._assigned = [False] * 3
+            self._host_digests = [_digest(m) for m in self._host_mats]
+            self._packed_for = ("band", self.BANDSIZE)
+        elif self._packed_for != ("band", self.BANDSIZE):
+            self.engine.pack_resident(self.BANDSIZE)
+            self._packed_for = ("band", self.BANDSIZE)
+
+    def _dense_apply(self, which: str, V, transpose=False):
+        """A_d V[d] (or A_d^T V[d]) with the current dense matrices: on the GPU while they are device-resident, with the
+        caller's arrays once those were overwritten."""
+        if self._dev_valid and not self._host_overrides():
+            return self.engine.dense_apply(which, V, transpose)
+        A = np.asarray({"C_inv": self.C_d_invs, "m": self.m_ds, "K_inv": self.K_d_invs}[which])
+        V = np.asarray(V, dtype=np.float64)
+        sub = "dji" if transpose else "dij"
+        return np.einsum(f"{sub},dj->di", A, V) if V.ndim == 2 else np.einsum(f"{sub},djp->dip", A, V)
 
     # ------------------------------------------------------------------------------------------
     def _fit_kernel_hparams(self, I, X_filled, verbose=False, num_iters: int = 1000):
@@ -165,10 +220,8 @@ class MAGI_v2:
         self.Xhat_init[:, self.observed_indicators] = self.X_interp_obs
         self.mu_ds[self.observed_indicators] = self.X_interp_obs.mean(axis=0)
 
-        self.C_d_invs = np.zeros((self.D, self.mag_I, self.mag_I))
-        self.m_ds = np.zeros((self.D, self.mag_I, self.mag_I))
-        self.K_d_invs = np.zeros((self.D, self.mag_I, self.mag_I))
-        self._build(self.observed_components, hp["phi1s"], hp["phi2s"])
+        self._band_applied = False
+        self._build(self.observed_components, hp["phi1s"], hp["phi2s"])        # (components not built yet are zero matrices, magi_v2.py:117-119)
 
         if np.all(self.observed_indicators):
             self.thetas_init = self._fit_thetas_init(theta_init_iters)
@@ -189,11 +242,11 @@ class MAGI_v2:
             self.sigma_sqs_init[self.unobserved_components] = hpu["sigma_sqs"]
             self.Xhat_init[:, self.unobserved_components] = self.X_interp_unobs
             self.mu_ds[self.unobserved_components] = self.X_interp_unobs.mean(axis=0)
-            self._build(self.unobserved_components, hpu["phi1s"], hpu["phi2s"])
+            self.engine.build_dense(self.I, self.D, list(self.unobserved_components), hpu["phi1s"], hpu["phi2s"], 2.01)
+            self._packed_for = None
 
         self._apply_band()
         self.Xhat_init = host.cubic_smoother(self.I, self.Xhat_init)
-        self._resident = None
 
     def _fit_thetas_init(self, iters: int) -> np.ndarray:
         """magi_v2.py:133-179: Adam(lr=.01) from theta = 1 on the t2 term, *including* the
@@ -204,8 +257,7 @@ class MAGI_v2:
         P, D, n = self.D_thetas, self.D, self.mag_I
         f_np, jac_np = self.drift.f_np, self.drift.jac_np
         Xc = (self.Xhat_init - self.mu_ds).T                                     # [D, n]
-        bvec = np.einsum("dij,dj->di", self.m_ds, Xc)                            # m_d x_c
-        Ks = np.asarray(self.K_d_invs) + np.transpose(np.asarray(self.K_d_invs), (0, 2, 1))
+        bvec = self._dense_apply("m", Xc)                                        # m_d x_c   (the N x N products run on the GPU)
         rng = np.random.default_rng(0)
         probe = rng.uniform(0.3, 2.0, size=P)
         cols = [f_np(self.I, self.Xhat_init, np.eye(P)[p]) for p in range(P)]
@@ -213,8 +265,8 @@ class MAGI_v2:
                   np.allclose(f_np(self.I, self.Xhat_init, probe), sum(probe[p] * cols[p] for p in range(P)), rtol=1e-12, atol=1e-14))
         if linear:
             F = np.stack([c.reshape(D, n) for c in cols], axis=-1)               # [D, n, P]   (the reshape quirk)
-            KF = np.einsum("dij,djp->dip", self.K_d_invs, F)
-            KTF = np.einsum("dji,djp->dip", self.K_d_invs, F)
+            KF = self._dense_apply("K_inv", F)
+            KTF = self._dense_apply("K_inv", F, transpose=True)
             A = np.einsum("dip,diq->pq", F, KF)
             g0 = np.einsum("dip,di->p", KF + KTF, bvec)                          # gradient offset
             grad_fn = lambda th: (A + A.T) @ th - g0
@@ -224,7 +276,8 @@ class MAGI_v2:
                 _, T = jac_np(self.Xhat_init, th)                                # [n, D, P]
                 Tq = np.stack([T[:, :, p].reshape(D, n) for p in range(P)], axis=-1)   # same reshape as the drift
                 r = fv - bvec
-                return np.einsum("dip,di->p", Tq, np.einsum("dij,dj->di", Ks, r))
+                g = self._dense_apply("K_inv", r) + self._dense_apply("K_inv", r, transpose=True)      # (K^-1 + K^-T) r on the GPU
+                return np.einsum("dip,di->p", Tq, g)
         theta = np.ones(P)
         m = np.zeros(P); v = np.zeros(P)
         b1, b2, lr, eps = 0.9, 0.999, 0.01, 1e-7
@@ -333,12 +386,9 @@ class MAGI_v2:
         self.phi1s, self.phi2s = np.array(phi1s_new, dtype=np.float64), np.array(phi2s_new, dtype=np.float64)
         self.mag_I = self.I.shape[0]
         self.beta = (self.D * self.mag_I) / self.N_ds.sum()
-        self.C_d_invs = np.zeros((self.D, self.mag_I, self.mag_I))
-        self.m_ds = np.zeros((self.D, self.mag_I, self.mag_I))
-        self.K_d_invs = np.zeros((self.D, self.mag_I, self.mag_I))
+        self._band_applied = False
         self._build(range(self.D), self.phi1s, self.phi2s)
         self._apply_band()
-        self._resident = None
 
     # reference helper names kept for callers that reach into them
     def _discretize(self, ts_obs, X_obs, discretization):

@@ -1284,32 +1284,48 @@ int magi_build_profile_get(double* flops, double* ms, long* calls) {
     return BC_COUNT;
 }
 
-int magi_build_matrices_device(magi_handle* h, const double* I, int N, int D, const double* phi1, const double* phi2,
-                               double nu, int bandsize, double* C_inv, double* m, double* K_inv) {
+int magi_ensure_dense(magi_handle* h, int N, int D) {
+    if (h->dDense[0] && h->dense_N == N && h->dense_D == D) return MAGI_OK;
+    const size_t nn = (size_t)N * N;
+    for (int k = 0; k < 3; ++k) { if (h->dDense[k]) (void)hipFree(h->dDense[k]); h->dDense[k] = nullptr; }
+    h->dense_N = h->dense_D = 0;
+    for (int k = 0; k < 3; ++k) {
+        MAGI_HIP_CHECK(h, hipMalloc(&h->dDense[k], nn * D * sizeof(double)));
+        MAGI_HIP_CHECK(h, hipMemset(h->dDense[k], 0, nn * D * sizeof(double)));       // components never built read as zero matrices
+    }
+    h->dense_N = N; h->dense_D = D;
+    return MAGI_OK;
+}
+
+// Eqn. 6 matrices of the components sel[0 .. n_sel) (phi1 / phi2 indexed like sel) into the handle's dense stacks
+int magi_build_dense_device(magi_handle* h, const double* I, int N, int D, int n_sel, const int* sel, const double* phi1, const double* phi2,
+                            double nu) {
     g_prof.on = getenv("MAGI_BUILD_PROFILE") != nullptr;
     if (g_prof.on) {
         if (!g_prof.e0) { (void)hipEventCreate(&g_prof.e0); (void)hipEventCreate(&g_prof.e1); }
         for (int i = 0; i < BC_COUNT; ++i) { g_prof.flops[i] = 0.0; g_prof.ms[i] = 0.0; g_prof.calls[i] = 0; }
     }
-    for (int d = 0; d < D; ++d)
+    for (int d = 0; d < n_sel; ++d) {
         if (!(phi1[d] > 0.0) || !(phi2[d] > 0.0)) return magi_fail(h, MAGI_E_BADARG, "phi1 and phi2 must be positive");
+        if (sel[d] < 0 || sel[d] >= D) return magi_fail(h, MAGI_E_BADARG, "component index out of range");
+    }
+    int rc0 = magi_ensure_dense(h, N, D);
+    if (rc0) return rc0;
     const size_t nn = (size_t)N * N;
     // The D components are independent and go through the SAME sequence of launches, so they are batched: every kernel of the
     // chain carries all components of a group on a grid axis (one stream, D times fewer launches, D times the tiles per launch:
     // the one-workgroup diagonal-block kernels of the components run side by side and the thin panels fill the GPU together).
     // B < D components per group when memory is short (or MAGI_BUILD_SERIAL is set): the groups follow each other.
-    DevBuf dI, dCinv, dM, dKinv;
+    DevBuf dI;
     MAGI_HIP_CHECK(h, dI.alloc(N));
-    MAGI_HIP_CHECK(h, dCinv.alloc(nn * D));
-    MAGI_HIP_CHECK(h, dM.alloc(nn * D));
-    MAGI_HIP_CHECK(h, dKinv.alloc(nn * D));
     MAGI_HIP_CHECK(h, hipMemcpy(dI.p, I, sizeof(double) * N, hipMemcpyHostToDevice));
-    int B = D;
+    // the batched launches address the components of a group at a constant stride: a group = a run of consecutive indices
+    int B = n_sel;
     {
         size_t free_b = 0, total_b = 0;
         const size_t per = (3 * nn + std::max((size_t)N * 128, nn / 2 + 128 * 128) + (size_t)((N + 127) / 128) * 128 * 128) * sizeof(double);
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            B = (int)std::max<size_t>(1, std::min<size_t>((size_t)D, (free_b / 10 * 9) / per));
+            B = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_sel, (free_b / 10 * 9) / per));
         if (getenv("MAGI_BUILD_SERIAL")) B = 1;
     }
     DevBuf Kap, P, PP;
@@ -1318,15 +1334,16 @@ int magi_build_matrices_device(magi_handle* h, const double* I, int N, int D, co
     MAGI_HIP_CHECK(h, PP.alloc(nn * B));
     Linalg la{};
     int rc = linalg_init(la, h, N, B, (long)nn);
-    std::vector<int> status((size_t)2 * D, -1);
-    for (int d0 = 0; d0 < D && rc == MAGI_OK; d0 += B) {
-        const int nb = std::min(B, D - d0);
+    std::vector<int> status((size_t)2 * n_sel, -1);
+    for (int d0 = 0; d0 < n_sel && rc == MAGI_OK;) {
+        int nb = 1;
+        while (nb < B && d0 + nb < n_sel && sel[d0 + nb] == sel[d0 + nb - 1] + 1) ++nb;
         la.batch = nb;
         for (int z = 0; z < nb && rc == MAGI_OK; ++z)
             rc = launch_matern(h, dI.p, N, phi1[d0 + z], phi2[d0 + z], nu, Kap.p + nn * z, P.p + nn * z, PP.p + nn * z);
-        double* Cd = dCinv.p + nn * d0;
-        double* Md = dM.p + nn * d0;
-        double* Kd = dKinv.p + nn * d0;
+        double* Cd = h->dDense[0] + nn * sel[d0];
+        double* Md = h->dDense[1] + nn * sel[d0];
+        double* Kd = h->dDense[2] + nn * sel[d0];
         // Kappa = L L^T, T = L^-1, C^-1 = Kappa^-1 = T^T T   (Kappa is consumed)            magi_v2.py:818, 126
         if (!rc) rc = potrf(la, Kap.p, "Kappa", true, 0);
         if (!rc) rc = trtri(la, Kap.p);
@@ -1370,16 +1387,27 @@ int magi_build_matrices_device(magi_handle* h, const double* I, int N, int D, co
         if (!rc && hipMemcpyAsync(&status[(size_t)2 * d0], la.status, (size_t)2 * nb * sizeof(int), hipMemcpyDeviceToHost, la.s) != hipSuccess)
             rc = magi_fail(h, MAGI_E_HIP, "build: status readback");
         if (!rc && hipStreamSynchronize(la.s) != hipSuccess) rc = magi_fail(h, MAGI_E_HIP, "build: synchronize");
+        d0 += nb;
     }
     linalg_free(la);
     if (rc) return rc;
-    for (int d = 0; d < D; ++d)
+    for (int d = 0; d < n_sel; ++d)
         for (int k = 0; k < 2; ++k)
             if (status[(size_t)2 * d + k] >= 0)
-                return magi_fail(h, MAGI_E_NOTSPD, std::string("Cholesky of ") + (k ? "K_d" : "Kappa") + " (component " + std::to_string(d) +
+                return magi_fail(h, MAGI_E_NOTSPD, std::string("Cholesky of ") + (k ? "K_d" : "Kappa") + " (component " + std::to_string(sel[d]) +
                                  "): non-positive pivot at index " + std::to_string(status[(size_t)2 * d + k]));
-    if (C_inv) MAGI_HIP_CHECK(h, hipMemcpy(C_inv, dCinv.p, nn * D * sizeof(double), hipMemcpyDeviceToHost));
-    if (m) MAGI_HIP_CHECK(h, hipMemcpy(m, dM.p, nn * D * sizeof(double), hipMemcpyDeviceToHost));
-    if (K_inv) MAGI_HIP_CHECK(h, hipMemcpy(K_inv, dKinv.p, nn * D * sizeof(double), hipMemcpyDeviceToHost));
-    return magi_pack_matrices(h, N, D, bandsize, dCinv.p, dM.p, dKinv.p);
+    return MAGI_OK;
+}
+
+int magi_build_matrices_device(magi_handle* h, const double* I, int N, int D, const double* phi1, const double* phi2,
+                               double nu, int bandsize, double* C_inv, double* m, double* K_inv) {
+    std::vector<int> sel(D);
+    for (int d = 0; d < D; ++d) sel[d] = d;
+    int rc = magi_build_dense_device(h, I, N, D, D, sel.data(), phi1, phi2, nu);
+    if (rc) return rc;
+    const size_t nn = (size_t)N * N;
+    if (C_inv) MAGI_HIP_CHECK(h, hipMemcpy(C_inv, h->dDense[0], nn * D * sizeof(double), hipMemcpyDeviceToHost));
+    if (m) MAGI_HIP_CHECK(h, hipMemcpy(m, h->dDense[1], nn * D * sizeof(double), hipMemcpyDeviceToHost));
+    if (K_inv) MAGI_HIP_CHECK(h, hipMemcpy(K_inv, h->dDense[2], nn * D * sizeof(double), hipMemcpyDeviceToHost));
+    return magi_pack_matrices(h, N, D, bandsize, h->dDense[0], h->dDense[1], h->dDense[2]);
 }

@@ -33,6 +33,8 @@ void free_dev(void* p) { if (p) (void)hipFree(p); }
 void free_matrices(magi_handle* h) {
     free_dev(h->dCsym); free_dev(h->dM); free_dev(h->dMt); free_dev(h->dKsym); free_dev(h->dYobs);
     free_dev(h->dTiles); free_dev(h->dTasks);
+    for (int k = 0; k < 3; ++k) { free_dev(h->dDense[k]); h->dDense[k] = nullptr; }
+    h->dense_N = h->dense_D = 0;
     h->dCsym = h->dM = h->dMt = h->dKsym = h->dYobs = nullptr;
     h->dTiles = nullptr; h->dTasks = nullptr;
     h->tiles_cap = h->tasks_cap = 0;
@@ -208,16 +210,74 @@ int magi_set_matrices(magi_handle* h, int N, int D, int bandsize, const double* 
     if (N < 2 || D < 1 || D > MAGI_MAX_D) return magi_fail(h, MAGI_E_BADARG, "need N >= 2 and 1 <= D <= " + std::to_string(MAGI_MAX_D));
     (void)hipSetDevice(h->device);
     const size_t bytes = (size_t)D * N * N * sizeof(double);
-    struct Tmp { double* p = nullptr; ~Tmp() { free_dev(p); } } dC, dm, dK;      // freed on every return path
-    MAGI_HIP_CHECK(h, hipMalloc(&dC.p, bytes));
-    MAGI_HIP_CHECK(h, hipMalloc(&dm.p, bytes));
-    MAGI_HIP_CHECK(h, hipMalloc(&dK.p, bytes));
-    MAGI_HIP_CHECK(h, hipMemcpy(dC.p, C_inv, bytes, hipMemcpyHostToDevice));
-    MAGI_HIP_CHECK(h, hipMemcpy(dm.p, m, bytes, hipMemcpyHostToDevice));
-    MAGI_HIP_CHECK(h, hipMemcpy(dK.p, K_inv, bytes, hipMemcpyHostToDevice));
-    int rc = magi_pack_matrices(h, N, D, bandsize, dC.p, dm.p, dK.p);
+    int rc = magi_ensure_dense(h, N, D);
+    if (rc) return rc;
+    MAGI_HIP_CHECK(h, hipMemcpy(h->dDense[0], C_inv, bytes, hipMemcpyHostToDevice));
+    MAGI_HIP_CHECK(h, hipMemcpy(h->dDense[1], m, bytes, hipMemcpyHostToDevice));
+    MAGI_HIP_CHECK(h, hipMemcpy(h->dDense[2], K_inv, bytes, hipMemcpyHostToDevice));
+    rc = magi_pack_matrices(h, N, D, bandsize, h->dDense[0], h->dDense[1], h->dDense[2]);
     (void)hipStreamSynchronize(h->stream);
     return rc;
+}
+
+int magi_build_dense(magi_handle* h, const double* I, int N, int D, int n_sel, const int32_t* sel, const double* phi1, const double* phi2, double nu) {
+    if (!h) return MAGI_E_BADARG;
+    if (!I || !sel || !phi1 || !phi2) return magi_fail(h, MAGI_E_BADARG, "null pointer");
+    if (N < 2 || D < 1 || D > MAGI_MAX_D || n_sel < 1 || n_sel > D) return magi_fail(h, MAGI_E_BADARG, "need N >= 2, 1 <= D <= " + std::to_string(MAGI_MAX_D) + " and 1 <= n_sel <= D");
+    if (!(nu > 1.0)) return magi_fail(h, MAGI_E_BADARG, "nu must exceed 1 (once-differentiable Matern)");
+    (void)hipSetDevice(h->device);
+    h->have_matrices = false;          // the packed operands no longer match the dense stacks until magi_pack_resident
+    h->sampler_ready = false;
+    std::vector<int> s(sel, sel + n_sel);
+    return magi_build_dense_device(h, I, N, D, n_sel, s.data(), phi1, phi2, nu);
+}
+
+int magi_pack_resident(magi_handle* h, int bandsize) {
+    if (!h) return MAGI_E_BADARG;
+    if (!h->dDense[0]) return magi_fail(h, MAGI_E_STATE, "no resident matrices: build or set them first");
+    (void)hipSetDevice(h->device);
+    int rc = magi_pack_matrices(h, h->dense_N, h->dense_D, bandsize, h->dDense[0], h->dDense[1], h->dDense[2]);
+    (void)hipStreamSynchronize(h->stream);
+    return rc;
+}
+
+int magi_get_dense(magi_handle* h, int bandsize, double* C_inv, double* m, double* K_inv) {
+    if (!h) return MAGI_E_BADARG;
+    if (!h->dDense[0]) return magi_fail(h, MAGI_E_STATE, "no resident matrices");
+    (void)hipSetDevice(h->device);
+    const int N = h->dense_N, D = h->dense_D;
+    const size_t nn = (size_t)N * N;
+    double* outs[3] = {C_inv, m, K_inv};
+    for (int k = 0; k < 3; ++k) {
+        if (!outs[k]) continue;
+        MAGI_HIP_CHECK(h, hipMemcpy(outs[k], h->dDense[k], nn * D * sizeof(double), hipMemcpyDeviceToHost));
+        if (bandsize >= 0)           // tf.linalg.band_part(., b, b), magi_v2.py:271-274
+            for (int d = 0; d < D; ++d)
+                for (int i = 0; i < N; ++i) {
+                    double* row = outs[k] + (size_t)d * nn + (size_t)i * N;
+                    for (int j = 0; j < std::min(N, i - bandsize); ++j) row[j] = 0.0;
+                    for (int j = std::max(0, i + bandsize + 1); j < N; ++j) row[j] = 0.0;
+                }
+    }
+    return MAGI_OK;
+}
+
+int magi_dense_apply(magi_handle* h, int which, int transpose, int nv, const double* V, double* Y) {
+    if (!h) return MAGI_E_BADARG;
+    if (!h->dDense[0]) return magi_fail(h, MAGI_E_STATE, "no resident matrices");
+    if (which < 0 || which > 2 || nv < 1 || nv > 8 || !V || !Y) return magi_fail(h, MAGI_E_BADARG, "which in 0..2, 1 <= nv <= 8, non-null vectors");
+    (void)hipSetDevice(h->device);
+    const size_t n = (size_t)h->dense_D * h->dense_N * nv;
+    double *dV = nullptr, *dY = nullptr;
+    struct Tmp { double*& p; ~Tmp() { free_dev(p); } } t1{dV}, t2{dY};
+    MAGI_HIP_CHECK(h, hipMalloc(&dV, n * sizeof(double)));
+    MAGI_HIP_CHECK(h, hipMalloc(&dY, n * sizeof(double)));
+    MAGI_HIP_CHECK(h, hipMemcpy(dV, V, n * sizeof(double), hipMemcpyHostToDevice));
+    int rc = magi_dense_apply_device(h, which, transpose, nv, dV, dY);
+    if (rc) return rc;
+    MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    MAGI_HIP_CHECK(h, hipMemcpy(Y, dY, n * sizeof(double), hipMemcpyDeviceToHost));
+    return MAGI_OK;
 }
 
 int magi_build_matrices(magi_handle* h, const double* I, int N, int D, const double* phi1, const double* phi2,
@@ -676,10 +736,10 @@ int magi_time_gradient(magi_handle* h, int n_chains, int reps, double* total_ms_
             for (int i = 0; i < reps; ++i) {
                 if (ph <= 3) rc = magi_launch_phase(h, ph, n_chains, h->stream);
                 else if (ph == 4) rc = magi_launch_finalize(h, n_chains, h->d_fin, h->stream);
-                else if (ph == 5) rc = magi_launch_stream(h, n_chains, 0, false, h->stream);
+                else if (ph == 5) rc = magi_launch_stream(h, n_chains, i & 1, false, h->stream);       // slot parity alternates as in the sampler (the block walk reverses)
                 else if (ph == 6) rc = magi_launch_leap_finalize(h, n_chains, h->d_fin, h->stream);
                 else if (ph == 7) rc = magi_launch_point(h, n_chains, 0, h->stream);
-                else rc = magi_launch_read_tiles(h, h->stream);
+                else rc = magi_launch_read_tiles(h, i & 1, h->stream);
                 if (rc) return rc;
             }
             MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t1, h->stream));

@@ -97,12 +97,18 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     // tile loads need nothing but the block index: on the wire before the plan-dependent loads (except in the waves that derive theta')
     const double2* A = reinterpret_cast<const double2*>(pb.tiles + (size_t)tix * TB * TB + (size_t)((threadIdx.x >> 6) * ST_RW) * TB) + (threadIdx.x & 63);
     constexpr int NCK = ST_RW / 8;
+    // Odd slots walk the wave's row chunks backwards: what a slot read LAST is what the next one reads FIRST, so the tail of the
+    // block stream is still in the XCD's L2 (4 MB against 9 MB of blocks per XCD; tools/micro/readshape.hip: 5-15 % on the
+    // load-only twin).  Chunk ck of the walk is physical chunk pc(ck); results are summed per PHYSICAL chunk so that they do
+    // not depend on the direction.  (Only the one- and two-chain instantiations: four chains have no registers for it.)
+    constexpr bool ALT = NC <= 2;
+    const int pc0 = (ALT && (parity & 1)) ? NCK - 1 : 0, pcs = (ALT && (parity & 1)) ? -1 : 1;
     double2 a0[8], a1[8];
     if ((threadIdx.x >> 6) >= NC) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) a0[r] = A[(size_t)r * (TB / 2)];
+        for (int r = 0; r < 8; ++r) a0[r] = A[(size_t)(pc0 * 8 + r) * (TB / 2)];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) a1[r] = A[(size_t)(8 + r) * (TB / 2)];
+        for (int r = 0; r < 8; ++r) a1[r] = A[(size_t)((pc0 + pcs) * 8 + r) * (TB / 2)];
     }
     __builtin_amdgcn_sched_barrier(0);
     const int d = task.x, kind = task.y, bi = task.z, bj = task.w;
@@ -169,9 +175,9 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
 #endif
     if (wave < NC) {                 // (the waves that derived theta' issue their first chunks now)
 #pragma unroll
-        for (int r = 0; r < 8; ++r) a0[r] = A[(size_t)r * (TB / 2)];
+        for (int r = 0; r < 8; ++r) a0[r] = A[(size_t)(pc0 * 8 + r) * (TB / 2)];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) a1[r] = A[(size_t)(8 + r) * (TB / 2)];
+        for (int r = 0; r < 8; ++r) a1[r] = A[(size_t)((pc0 + pcs) * 8 + r) * (TB / 2)];
     }
     __builtin_amdgcn_sched_barrier(0);
     double thv[NC][P];
@@ -199,40 +205,57 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     }
     __syncthreads();
 
-    double2 vc[NC], cacc[NC];
+    constexpr int NACC = ALT ? NCK : 1;            // column accumulators per physical chunk (direction-independent sums)
+    double2 vc[NC], cacc[NC][NACC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         vc[c] = *reinterpret_cast<const double2*>(&vcol[c][2 * lane]);
-        cacc[c].x = 0.0; cacc[c].y = 0.0;
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) { cacc[c][k].x = 0.0; cacc[c][k].y = 0.0; }
     }
 #pragma unroll
     for (int ck = 0; ck < NCK; ++ck) {
         double2 (&a)[8] = (ck & 1) ? a1 : a0;
+        const int row0 = wave * ST_RW + (pc0 + pcs * ck) * 8;          // first row of this chunk inside the block
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             double p[8];
+            double2& acc = cacc[c][ALT ? ck : 0];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const double2 ar = a[r];
                 p[r] = fma(ar.y, vc[c].y, ar.x * vc[c].x);
-                const double xr = vrow[c][wave * ST_RW + ck * 8 + r];
-                cacc[c].x = fma(ar.x, xr, cacc[c].x);
-                cacc[c].y = fma(ar.y, xr, cacc[c].y);
+                const double xr = vrow[c][row0 + r];
+                acc.x = fma(ar.x, xr, acc.x);
+                acc.y = fma(ar.y, xr, acc.y);
             }
             const double s = tsum8(p, lane);
             // all 8 lanes of a group hold the same bits (commutative butterflies): an unconditional store keeps the loop
             // free of branches (with them LLVM sinks the column accumulators behind the loop and the tile stays live)
-            rowout[c][wave * ST_RW + ck * 8 + (lane >> 3)] = s;
+            rowout[c][row0 + (lane >> 3)] = s;
         }
         __builtin_amdgcn_sched_barrier(0);
         if (ck + 2 < NCK) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) a[r] = A[(size_t)((ck + 2) * 8 + r) * (TB / 2)];
+            for (int r = 0; r < 8; ++r) a[r] = A[(size_t)((pc0 + pcs * (ck + 2)) * 8 + r) * (TB / 2)];
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int c = 0; c < NC; ++c) *reinterpret_cast<double2*>(&colacc[wave][c][2 * lane]) = cacc[c];
+    for (int c = 0; c < NC; ++c) {
+        double2 tot = cacc[c][0];
+        if (ALT) {
+            // physical chunk order 0, 1, .., NCK - 1 whatever the walk was: walk index of physical chunk k is k (even slots) or NCK - 1 - k
+            const bool rev = (parity & 1) != 0;
+            tot = rev ? cacc[c][NCK - 1] : cacc[c][0];
+#pragma unroll
+            for (int k = 1; k < NACC; ++k) {
+                const double2 nx = rev ? cacc[c][NCK - 1 - k] : cacc[c][k];
+                tot.x += nx.x; tot.y += nx.y;
+            }
+        }
+        *reinterpret_cast<double2*>(&colacc[wave][c][2 * lane]) = tot;
+    }
     __syncthreads();
 
     // partials: threads [0, TB) the row-type output (block row bi, slot bj), threads [TB, 2 TB) the
@@ -527,11 +550,12 @@ __global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains c
 
 // load-only twin of k_stream's tile stream (bench.py's ceiling leg): every workgroup reads its 128 KB block with the same
 // 16-B-per-lane pattern and does nothing else -- what the memory system delivers for this layout and working set
-__global__ __launch_bounds__(256) void k_read_tiles(const double2* __restrict__ p, double* out) {
+__global__ __launch_bounds__(256) void k_read_tiles(const double2* __restrict__ p, double* out, int rev) {
     const double2* q = p + (size_t)blockIdx.x * (MAGI_TB * MAGI_TB / 2) + threadIdx.x;
     double a = 0.0;
+    constexpr int R = MAGI_TB * MAGI_TB / 2 / 256;
 #pragma unroll
-    for (int r = 0; r < MAGI_TB * MAGI_TB / 2 / 256; ++r) { const double2 v = q[r * 256]; a += v.x + v.y; }
+    for (int r = 0; r < R; ++r) { const double2 v = q[(rev ? R - 1 - r : r) * 256]; a += v.x + v.y; }     // (odd launches walk backwards, as k_stream does)
     if (a == 12345.678) out[0] = a;
 }
 
@@ -633,8 +657,8 @@ int magi_launch_point(magi_handle* h, int n_chains, int parity, hipStream_t s) {
     return MAGI_OK;
 }
 
-int magi_launch_read_tiles(magi_handle* h, hipStream_t s) {
-    hipLaunchKernelGGL(k_read_tiles, dim3(h->pb.n_tasks), dim3(256), 0, s, reinterpret_cast<const double2*>(h->pb.tiles), h->d_fin);
+int magi_launch_read_tiles(magi_handle* h, int rev, hipStream_t s) {
+    hipLaunchKernelGGL(k_read_tiles, dim3(h->pb.n_tasks), dim3(256), 0, s, reinterpret_cast<const double2*>(h->pb.tiles), h->d_fin, rev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("read_tiles launch: ") + hipGetErrorString(e));
     return MAGI_OK;

@@ -724,6 +724,10 @@ struct magi_handle {
     DevProblem pb{};
     double *dCsym = nullptr, *dM = nullptr, *dMt = nullptr, *dKsym = nullptr, *dYobs = nullptr;
     size_t mat_elems = 0;
+    // dense C^-1, m, K^-1 ([D][N][N], unmasked) as built or uploaded: authoritative until the caller uploads others; packed
+    // (band mask, symmetrised / transposed copies, single-phase operator blocks) by magi_pack_matrices
+    double* dDense[3] = {nullptr, nullptr, nullptr};
+    int dense_N = 0, dense_D = 0;
     double* dTiles = nullptr;
     int* dTasks = nullptr;
     size_t tiles_cap = 0, tasks_cap = 0;
@@ -775,7 +779,7 @@ int magi_build_profile_get(double* flops, double* ms, long* calls);           //
 int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const double* X, const double* mu, const double* mu_phi2,
                             const double* sd_phi2, const double* sig_loc, double nu, int iters, double lr, double jitter,
                             double* phi1, double* phi2, double* sig2, double* loss_trace);
-int magi_launch_read_tiles(magi_handle* h, hipStream_t s);                     // load-only pass over the packed operator blocks
+int magi_launch_read_tiles(magi_handle* h, int rev, hipStream_t s);                     // load-only pass over the packed operator blocks
 int magi_launch_plan_eval(magi_handle* h, int n_chains, hipStream_t s);        // plan: evaluate buffer 0, no leapfrog                                       // workgroups along the grid axis
 // build.hip: E = Ks M, H = Cs + M^T E for D dense [N][N] components (H overwrites Cs)
 int magi_fused_operators(magi_handle* h, int N, int D, double* dCs_inout_H, const double* dM, const double* dKs, double* dE);
@@ -788,5 +792,11 @@ int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double*
 int magi_build_matrices_device(magi_handle* h, const double* I, int N, int D, const double* phi1,
                                const double* phi2, double nu, int bandsize, double* C_inv, double* m,
                                double* K_inv);
+// build.hip: the listed components of the resident dense stacks (allocated / zeroed when N, D change); no packing
+int magi_build_dense_device(magi_handle* h, const double* I, int N, int D, int n_sel, const int* sel, const double* phi1,
+                            const double* phi2, double nu);
+int magi_ensure_dense(magi_handle* h, int N, int D);
+// pack.hip: Y[d] = A_d V[d] or A_d^T V[d] for the resident dense stack `which` (0 C^-1, 1 m, 2 K^-1); V, Y device [D][N][nv]
+int magi_dense_apply_device(magi_handle* h, int which, int trans, int nv, const double* dV, double* dY);
 int magi_matern_blocks_device(magi_handle* h, const double* I, int N, double phi1, double phi2, double nu,
                               double* Kappa, double* p_Kappa, double* Kappa_pp);

@@ -48,7 +48,55 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const double* __restrict__ H
     }
 }
 
+// Y[d][i][v] = sum_j A_d[i][j] V[d][j][v]  (TRANS: A_d[j][i]), v < NV <= 8.  One wave per output row: the plain product sums
+// along the wave (lane = column, butterfly), the transposed one keeps lane = row of the output and walks the rows of A
+// (both read A along its unit-stride dimension).  grid (ceil(N / 4), D), 256 threads.
+template <int TRANS>
+__global__ __launch_bounds__(256) void k_dense_apply(const double* __restrict__ A, const double* __restrict__ V, double* __restrict__ Y, int N, int nv) {
+    const int d = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double* Ad = A + (size_t)d * N * N;
+    const double* Vd = V + (size_t)d * N * nv;
+    double* Yd = Y + (size_t)d * N * nv;
+    if (!TRANS) {
+        const int row = blockIdx.x * 4 + wave;
+        if (row >= N) return;
+        double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int j = lane; j < N; j += 64) {
+            const double a = Ad[(size_t)row * N + j];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) if (v < nv) acc[v] = fma(a, Vd[(size_t)j * nv + v], acc[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            if (v >= nv) break;
+            const double sres = wave_sum(acc[v]);
+            if (lane == 0) Yd[(size_t)row * nv + v] = sres;
+        }
+    } else {
+        // 256 consecutive output rows (= columns of A) per workgroup: thread = column, loop over the rows of A
+        const int col = blockIdx.x * 256 + threadIdx.x;
+        if (col >= N) return;
+        double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < N; ++i) {
+            const double a = Ad[(size_t)i * N + col];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) if (v < nv) acc[v] = fma(a, Vd[(size_t)i * nv + v], acc[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < 8; ++v) if (v < nv) Yd[(size_t)col * nv + v] = acc[v];
+    }
+}
+
 }  // namespace
+
+int magi_dense_apply_device(magi_handle* h, int which, int trans, int nv, const double* dV, double* dY) {
+    const int N = h->dense_N, D = h->dense_D;
+    if (trans) hipLaunchKernelGGL(k_dense_apply<1>, dim3((N + 255) / 256, D), dim3(256), 0, h->stream, h->dDense[which], dV, dY, N, nv);
+    else hipLaunchKernelGGL(k_dense_apply<0>, dim3((N + 3) / 4, D), dim3(256), 0, h->stream, h->dDense[which], dV, dY, N, nv);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("dense apply launch: ") + hipGetErrorString(e));
+    return MAGI_OK;
+}
 
 int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double* dC_inv, const double* dM,
                        const double* dK_inv) {

@@ -48,6 +48,10 @@ _SYMBOLS = {
     "magi_fit_hparams": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_double,
                                    C.c_double, _dp, _dp, _dp, _dp]),
     "magi_set_matrices": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]),
+    "magi_build_dense": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, C.c_int, _ip, _dp, _dp, C.c_double]),
+    "magi_pack_resident": (C.c_int, [C.c_void_p, C.c_int]),
+    "magi_get_dense": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
+    "magi_dense_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp]),
     "magi_set_problem": (C.c_int, [C.c_void_p, _dp, _dp, _lp, _dp, C.c_int64, C.c_double, _dp, C.c_int, C.c_int]),
     "magi_logpost_grad": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp]),
     "magi_logpost_grad_fused": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp]),
@@ -167,6 +171,36 @@ class MagiEngine:
                                                   *[_ptr(o) for o in outs]))
         self.N, self.D = N, D
         return tuple(outs) if want_host else None
+
+    def build_dense(self, I, D, comps, phi1s, phi2s, nu=2.01):
+        """Matrices of the listed components into the device-resident dense stacks of a D-component problem (no host copy,
+        no packing): magi_v2.py:122-128 / 262-268 / 447-451."""
+        I = _f64(np.asarray(I).reshape(-1))
+        comps = np.ascontiguousarray(comps, dtype=np.int32)
+        phi1s, phi2s = _f64(phi1s, comps.shape), _f64(phi2s, comps.shape)
+        self._check(self._lib.magi_build_dense(self._h, _ptr(I), I.shape[0], int(D), comps.shape[0], comps.ctypes.data_as(_ip),
+                                               _ptr(phi1s), _ptr(phi2s), float(nu)))
+        self.N, self.D = I.shape[0], int(D)
+
+    def pack_resident(self, bandsize=None):
+        """Band mask (magi_v2.py:271-274) + packing of the resident dense stacks."""
+        self._check(self._lib.magi_pack_resident(self._h, -1 if bandsize is None else int(bandsize)))
+
+    def get_dense(self, bandsize=None):
+        """Host copies (C_inv, m, K_inv), each [D, N, N], of the resident stacks with the band mask applied."""
+        outs = [np.empty((self.D, self.N, self.N)) for _ in range(3)]
+        self._check(self._lib.magi_get_dense(self._h, -1 if bandsize is None else int(bandsize), *[_ptr(o) for o in outs]))
+        return tuple(outs)
+
+    def dense_apply(self, which, V, transpose=False):
+        """Y[d] = A_d V[d] (or A_d^T V[d]) for the resident stack ``which`` in ("C_inv", "m", "K_inv"); V [D, N] or [D, N, nv]."""
+        V = _f64(V)
+        vec = V.ndim == 2
+        V3 = V[:, :, None] if vec else V
+        V3 = _f64(V3, (self.D, self.N, V3.shape[2]))
+        Y = np.empty_like(V3)
+        self._check(self._lib.magi_dense_apply(self._h, ("C_inv", "m", "K_inv").index(which), int(bool(transpose)), V3.shape[2], _ptr(V3), _ptr(Y)))
+        return Y[:, :, 0] if vec else Y
 
     def fit_hparams(self, I, X_filled, mu, mu_phi2, sd_phi2, sigma_sq_loc, phi1_init, phi2_init, sigma_sq_init, nu=2.01,
                     num_iters=1000, learning_rate=0.01, jitter=1e-6, want_trace=False):

@@ -73,7 +73,10 @@ def test_predict_returns_the_reference_results_dictionary(fitted):
     # same seed -> same chain; several chains -> leading axis, chain 0 unchanged
     res2 = model.predict(num_results=30, num_burnin_steps=30, seed=7, n_chains=3)
     assert res2["X_samps"].shape == (3, 30, 161, 3)
-    np.testing.assert_array_equal(res2["thetas_samps"][0], res["thetas_samps"])
+    # (three or more chains per GPU run the matrix-core streaming kernel, one or two the one-chain kernel: another summation
+    #  order, the same chain to rounding -- bit-identity holds between batches of the same kernel family, tests/test_fullsize_gpu.py)
+    np.testing.assert_allclose(res2["thetas_samps"][0], res["thetas_samps"], rtol=1e-6)
+    np.testing.assert_array_equal(res2["kernel_results"]["leapfrogs_taken"][0], res["kernel_results"]["leapfrogs_taken"])
     assert not np.allclose(res2["thetas_samps"][1], res["thetas_samps"])
 
 
@@ -116,3 +119,38 @@ def test_update_kernel_matrices_for_forecasting(fitted):
     Kap, _, _ = orc.matern_blocks(model.I, model.phi1s[1], model.phi2s[1], 2.01)
     dense = model.engine.build_matrices(model.I, model.phi1s[1:2], model.phi2s[1:2], 2.01)[0][0]
     assert np.abs(dense @ Kap - np.eye(181)).max() < 1e-6
+
+
+def test_matrices_stay_on_the_device_until_read_and_edits_are_seen():
+    """The Eqn.-6 matrices are built into the handle and packed there; C_d_invs / m_ds / K_d_invs are host mirrors that are
+    downloaded on first read (band-masked, as the reference's attributes are after initial_fit) and uploaded again only
+    when the caller assigned one or edited a downloaded copy in place (magi_v2.py:77-80)."""
+    import magi_v2
+    g = np.load(os.path.join(GOLDEN, "g3_pipeline.npz"))
+    model = magi_v2.MAGI_v2(D_thetas=3, ts_obs=g["seir3_ts_obs"], X_obs=g["seir3_X_obs"], bandsize=80, f_vec="seir3")
+    model.initial_fit(discretization=1, hparam_iters=0)
+    assert all(m is None for m in model._host_mats)                          # nothing crossed PCIe
+    base = model.predict(num_results=6, num_burnin_steps=6, seed=11)
+    assert all(m is None for m in model._host_mats)
+    # the N x N products of the theta initialiser ran on the device copies: same numbers as numpy on a download
+    Cd, md, Kd = model.engine.get_dense(None)
+    V = np.random.default_rng(0).standard_normal((3, 161, 2))
+    np.testing.assert_allclose(model.engine.dense_apply("m", V), np.einsum("dij,djp->dip", md, V), rtol=1e-12, atol=1e-12 * np.abs(md).max())
+    np.testing.assert_allclose(model.engine.dense_apply("K_inv", V[:, :, 0], transpose=True), np.einsum("dji,dj->di", Kd, V[:, :, 0]), rtol=1e-12,
+                               atol=1e-12 * np.abs(Kd).max())
+    # first read downloads the masked matrices
+    C = model.C_d_invs
+    i = np.arange(161)
+    assert C.shape == (3, 161, 161) and (C[:, np.abs(i[:, None] - i[None, :]) > 80] == 0).all()
+    np.testing.assert_array_equal(C[:, np.abs(i[:, None] - i[None, :]) <= 80], Cd[:, np.abs(i[:, None] - i[None, :]) <= 80])
+    same = model.predict(num_results=6, num_burnin_steps=6, seed=11)        # reading alone changes nothing
+    np.testing.assert_array_equal(same["thetas_samps"], base["thetas_samps"])
+    # an in-place edit of the downloaded copy is detected (full-content hash) and uploaded
+    model.C_d_invs[0] *= 1.5
+    edited = model.predict(num_results=6, num_burnin_steps=6, seed=11)
+    assert not np.array_equal(edited["X_samps"], base["X_samps"])
+    # assigning the original back restores the original chain
+    model.C_d_invs = C / np.array([1.5, 1.0, 1.0])[:, None, None]
+    back = model.predict(num_results=6, num_burnin_steps=6, seed=11)
+    np.testing.assert_allclose(back["thetas_samps"], base["thetas_samps"], rtol=1e-9)
+    model.engine.close()

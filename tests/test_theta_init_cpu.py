@@ -83,9 +83,12 @@ def test_fit_thetas_init_general_branch_equals_oracle():
         J, T = complex_step_jacobians(fitzhugh_nagumo, np.asarray(Xa, dtype=np.float64), np.asarray(th, dtype=np.float64))
         return np.asarray(fitzhugh_nagumo(None, Xa, th), dtype=np.float64), J, T
     orc.DRIFTS["fhn_cpu"] = (fn, 2, 3)
-    model = _model(fitzhugh_nagumo, 2, 3, X, mu, m, K_inv, I)
-    got = model._fit_thetas_init(200)
-    want, losses = orc.fit_thetas_init(X, mu, m, K_inv, "fhn_cpu", 3, num_iters=200)
+    try:
+        model = _model(fitzhugh_nagumo, 2, 3, X, mu, m, K_inv, I)
+        got = model._fit_thetas_init(200)
+        want, losses = orc.fit_thetas_init(X, mu, m, K_inv, "fhn_cpu", 3, num_iters=200)
+    finally:
+        del orc.DRIFTS["fhn_cpu"]
     np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-10)
     assert np.abs(want - 1.0).max() > 0.5 and losses[-1] < losses[0]           # 200 steps of lr .01 moved every entry
 
