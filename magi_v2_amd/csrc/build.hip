@@ -182,6 +182,8 @@ struct GemmArgs {
                        // 2: k < m0 + 128 (A lower-triangular in (m, k)) ; 3: k >= n0 (B(n,k) zero for k < n) ;
                        // 4: k < n0 + 128 (B(n,k) zero for k > n)
     long batchA, batchB, batchC;   // element strides between grid.z batches
+    double* C2; long ldc2, batchC2t;   // optional second output, TRANSPOSED: C2[n * ldc2 + m] = alpha * sum (the Cholesky panels are kept in
+                                   // both orientations: the rank-k updates then read both operands along their unit-stride dimension)
     int remap;                     // set by launch_gemm: XCD-aware super-block tile order (large tile grids)
     int zinner;                    // > 0: grid.z = zinner x outer; batch* step the inner index, batch*2 the outer one
     long batchA2, batchB2, batchC2;
@@ -278,7 +280,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, const double* A
 // element the load -> store order must be kept, 64 dependent round trips per thread, several times the MFMA time of a K = 128
 // update.
 template <bool FULL>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, double* C, int m0, int n0, const d4 (&acc)[4][4]) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, double* C, double* C2, int m0, int n0, const d4 (&acc)[4][4]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int lr = lane & 15, lk = lane >> 4;
@@ -292,6 +294,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, double* C, int 
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (FULL || (mrel + 16 * i + 4 * r < g.M && nrel + 16 * j < g.N)) c0[(long)(16 * i + 4 * r) * g.ldc + 16 * j] = g.alpha * acc[i][j][r];
+        if (C2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (FULL || (mrel + 16 * i + 4 * r < g.M && nrel + 16 * j < g.N))
+                            C2[(long)(nrel + 16 * j) * g.ldc2 + mrel + 16 * i + 4 * r] = g.alpha * acc[i][j][r];
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -371,8 +383,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAGI_GEMM_O
     const bool interior = (m0 + GT <= g.M) && (n0 + GT <= g.N) && ((kend - kbeg) % GK == 0);
     if (interior) gemm_mainloop<true>(g, A, B, m0, n0, kbeg, kend, As, Bs, acc);
     else gemm_mainloop<false>(g, A, B, m0, n0, kbeg, kend, As, Bs, acc);
-    if ((m0 + GT <= g.M) && (n0 + GT <= g.N)) gemm_epilogue<true>(g, C, m0, n0, acc);
-    else gemm_epilogue<false>(g, C, m0, n0, acc);
+    double* C2 = g.C2 ? g.C2 + (long)zi * g.batchC2t : nullptr;
+    if ((m0 + GT <= g.M) && (n0 + GT <= g.N)) gemm_epilogue<true>(g, C, C2, m0, n0, acc);
+    else gemm_epilogue<false>(g, C, C2, m0, n0, acc);
 }
 
 // =============================================================================================
@@ -834,10 +847,11 @@ int launch_gemm(magi_handle* h, hipStream_t s, const GemmArgs& g_in, int batch =
 }
 
 // In-place lower Cholesky of the la.batch matrices A + z la.bsA (N x N row-major, ld = N), all of them in every launch.
-// Right-looking over block columns of 256 = two 128-wide panels: the 128 x 128 diagonal blocks are factorised AND inverted by
-// k_diag_chol_inv (one workgroup per component), a panel is solved as a GEMM with that inverse, the second panel of a pair
-// takes the first one's rank-128 update on its own, and the trailing matrix takes BOTH panels in one rank-256 SYRK update on
-// the matrix cores -- twice the flops per byte of the trailing matrix's read-modify-write of a rank-128 sweep.
+// Right-looking over block columns of 512 = four 128-wide panels, left-looking inside a block column: the 128 x 128 diagonal
+// blocks are factorised AND inverted by k_diag_chol_inv (one workgroup per component), a panel is solved as a GEMM with that
+// inverse, panel c of a block column first takes the rank-128c update of the panels before it (a tall 128-wide GEMM), and the
+// trailing matrix takes all four panels in ONE rank-512 SYRK update on the matrix cores -- four times the flops per byte of the
+// trailing matrix's read-modify-write of a rank-128 sweep.
 // The inverses of the diagonal blocks stay in la.dinv for the triangular inverse that follows.
 int potrf_status(Linalg& la, const char* what, int status_slot = 0) {
     magi_handle* h = la.h;
@@ -865,7 +879,8 @@ int potrf(Linalg& la, double* A, const char* what, bool defer_status = false, in
                            la.dinv + (size_t)(j0 / NB) * 128 * 128, la.status + status_slot, j0, la.bsA, la.bs_dinv, 2);
         prof_end(la.s, BC_DIAG, (double)n * n * n * la.batch);        // n^3/3 factor + 2 n^3/3 inverse
     };
-    auto panel = [&](int j0, int n, int row0) -> int {               // rows >= row0 of block column j0 <- . Linv_jj^T
+    auto panel = [&](int jblk, int j0, int n, int row0) -> int {     // rows >= row0 of block column j0 <- . Linv_jj^T
+        (void)jblk;
         GemmArgs g{};
         double* P = A + (size_t)row0 * N + j0;
         g.A = P; g.sAm = N; g.sAk = 1;
@@ -874,6 +889,8 @@ int potrf(Linalg& la, double* A, const char* what, bool defer_status = false, in
         g.batchA = la.bsA; g.batchB = la.bs_dinv; g.batchC = la.bsA;
         return launch_gemm(h, la.s, g, la.batch, BC_PANEL);
     };
+    // (a transposed copy of the panels, so that this update reads both operands along their unit-stride dimension, was measured:
+    //  no gain -- 34.6 against 34.1 ms at N = 8192 -- the rank-k updates are bound by the tall thin launches inside a block column)
     auto syrk = [&](int row0, int ncols, int k0, int K) -> int {     // A[row0.., row0 .. row0 + ncols) -= A[row0.., k0 .. k0+K) A[row0 .. row0+ncols, k0 .. k0+K)^T (lower tiles)
         GemmArgs t{};
         double* P = A + (size_t)row0 * N + k0;
@@ -884,20 +901,22 @@ int potrf(Linalg& la, double* A, const char* what, bool defer_status = false, in
         t.batchA = la.bsA; t.batchB = la.bsA; t.batchC = la.bsA;
         return launch_gemm(h, la.s, t, la.batch, BC_TRAIL);
     };
+    // outer block column = NPAN panels of 128 (left-looking inside it: panel c first takes the rank-128c update of the panels
+    // before it), then ONE rank-(128 NPAN) update of the trailing matrix
+    static const int NPAN = [] { const char* e = getenv("MAGI_POTRF_PANELS"); const int v = e ? atoi(e) : 4; return std::max(1, std::min(v, 16)); }();
     int rc = MAGI_OK;
-    for (int j0 = 0; j0 < N && rc == MAGI_OK; j0 += 2 * NB) {
-        const int n1 = std::min(NB, N - j0);
-        diag(j0, n1);
-        const int j1 = j0 + NB;
-        if (j1 >= N) break;
-        if ((rc = panel(j0, n1, j1))) break;
-        const int n2 = std::min(NB, N - j1);
-        if ((rc = syrk(j1, n2, j0, NB))) break;                        // second panel of the pair: rank-128 update from the first
-        diag(j1, n2);
-        const int j2 = j1 + NB;
-        if (j2 >= N) break;
-        if ((rc = panel(j1, n2, j2))) break;
-        rc = syrk(j2, N - j2, j0, 2 * NB);                             // trailing matrix: both panels, rank 256
+    for (int j0 = 0; j0 < N && rc == MAGI_OK; j0 += NPAN * NB) {
+        for (int c = 0; c < NPAN && rc == MAGI_OK; ++c) {
+            const int jc = j0 + c * NB;
+            if (jc >= N) break;
+            const int nc = std::min(NB, N - jc);
+            if (c > 0 && (rc = syrk(jc, nc, j0, c * NB))) break;
+            diag(jc, nc);
+            if (jc + NB < N) rc = panel(j0, jc, nc, jc + NB);
+        }
+        const int jn = j0 + NPAN * NB;
+        if (rc || jn >= N) break;
+        rc = syrk(jn, N - jn, j0, NPAN * NB);
     }
     if (rc) return rc;
     hipError_t e = hipGetLastError();
