@@ -75,15 +75,67 @@ def test_fit_increases_the_marginal_likelihood(data):
     eng.close()
 
 
-def test_vignette_end_to_end_with_fitted_hyperparameters():
-    """vignette.ipynb cells 5-11 through the drop-in API: bandsize 80, discretization 1, NUTS with annealing,
-    4 chains x (300 + 300).  The notebook's stored (stale, unseeded) output printed theta = (5.831, 0.565, 1.77)
-    for the truth (6, 0.6, 1.8).
+def _vignette_run(fit_kw, theta_init, stale_cache=True, burnin=1000, results=1000, chains=4, seed=123):
+    """vignette.ipynb cells 5-11 through the drop-in API at the reference's own length (cell 8: 1000 + 1000 NUTS steps,
+    bandsize 80, discretization 1) on the vignette rows; returns (model, theta mean [3], per-chain means [chains, 3])."""
+    import magi_v2
+    g = np.load(os.path.join(GOLDEN, "g3_pipeline.npz"))
+    model = magi_v2.MAGI_v2(D_thetas=3, ts_obs=g["seir3_ts_obs"], X_obs=g["seir3_X_obs"], bandsize=80, f_vec="seir3")
+    model.initial_fit(discretization=1, **fit_kw)
+    if theta_init is not None:
+        model.thetas_init = np.asarray(theta_init, dtype=np.float64)
+    res = model.predict(num_results=results, num_burnin_steps=burnin, n_chains=chains, seed=seed, stale_cache=stale_cache)
+    th = res["thetas_samps"].reshape(chains, results, 3)
+    assert np.isfinite(res["X_samps"]).all() and np.isfinite(th).all()
+    kr = res["kernel_results"]
+    assert np.asarray(kr["has_divergence"]).mean() < 0.05
+    return model, th.reshape(-1, 3).mean(axis=0), th.mean(axis=1)
 
-    * reference-faithful defaults (fit on the interpolated grid, the reference's theta initialiser) must run and
-      stay finite; with the restated fit they do NOT recover theta (documented in DESIGN.md section 8);
-    * with the hyper-parameters fitted on the observed rows and theta_init overridden (both documented user
-      choices, magi_v2.py:77-80) the posterior mean lands where the notebook's did."""
+
+# Recovered parameters at the reference's length, 4 chains x (1000 + 1000), seed 123 (profiles/r02_recovery_full_length.json;
+# MC standard errors from batch means).  The reference's stored notebook output for this data is (5.831, 0.565, 1.77) for the
+# truth (6, 0.6, 1.8) (vignette.ipynb cell 11) -- from an unseeded run whose hyper-parameters are not recorded anywhere.
+REFERENCE_PRINTED = np.array([5.831, 0.565, 1.77])
+
+
+def test_recovery_at_reference_length_phi2_half_true_noise():
+    """phi2 = 0.5 and the true noise level, theta_init = 1: measured (5.805 +- 0.031, 0.554 +- 0.002, 1.749 +- 0.005) -- the
+    hot path (build, log posterior, NUTS, annealing) lands where the reference's notebook did."""
+    g = np.load(os.path.join(GOLDEN, "g3_pipeline.npz"))
+    true_sd = 0.05 * np.ptp(g["rows"][:, 6:9], axis=0)
+    model, th, per_chain = _vignette_run(dict(hparams={"phi2s": [0.5, 0.5, 0.5], "sigma_sqs": true_sd ** 2}, theta_init_iters=0), np.ones(3))
+    print("theta", th, "per chain", per_chain)
+    np.testing.assert_allclose(th, [5.805, 0.554, 1.749], atol=0, rtol=0.03)            # the recorded run (>= 5 MC standard errors)
+    assert np.all(np.abs(th - REFERENCE_PRINTED) < [0.2, 0.025, 0.06]), th              # and the reference's printed values
+    model.engine.close()
+
+
+def test_recovery_at_reference_length_starting_hyperparameters():
+    """hparam_iters = 0 (the reference's STARTING hyper-parameters: phi2 = (0.375, 0.23, 0.109), sigma^2 = (0.1 std)^2),
+    theta_init = 1: measured (4.167 +- 0.057, 0.235 +- 0.016, 1.192 +- 0.022) with the reference's stale-cache quirk and
+    (4.221, 0.256, 1.217) without -- NOT the notebook's values: recovery depends on the hyper-parameters, not on the sampler."""
+    model, th, per_chain = _vignette_run(dict(hparam_iters=0, theta_init_iters=0), np.ones(3))
+    print("theta", th, "per chain", per_chain)
+    assert np.all(np.abs(th - [4.167, 0.235, 1.192]) < [0.35, 0.09, 0.13]), th           # ~6 MC standard errors of the recorded run
+    assert np.all(np.abs(per_chain - th) < [0.5, 0.15, 0.2])                             # the four chains agree with each other
+    model.engine.close()
+
+
+@pytest.mark.xfail(strict=True, reason="reference-default path (hyper-parameters fitted on the interpolated grid + the reference's theta "
+                   "initialiser): measured theta = (0.24, 0.02, 0.11) at 4 x (1000 + 1000), against the notebook's (5.831, 0.565, 1.77). "
+                   "The restated fit finds phi2 = (0.79, 0.16, 0.09) with near-zero noise (its objective there is 3692 against 3329 at "
+                   "phi2 = 0.5 + true noise) and the initialiser's reshape (magi_v2.py:155-156) returns negative theta, which the -5.0 "
+                   "fallback (:379-380) turns into theta ~ 0.007.  TFP / tf_keras are not installable: f1 / f2 / sampler parity unpinned.")
+def test_default_path_recovers_the_notebook_values():
+    model, th, per_chain = _vignette_run(dict(), None)
+    print("theta", th, "phi2", model.phi2s, "thetas_init", model.thetas_init)
+    assert np.all(np.abs(th - REFERENCE_PRINTED) < [0.6, 0.06, 0.2]), th
+
+
+def test_vignette_end_to_end_with_fitted_hyperparameters():
+    """vignette.ipynb cells 5-8 through the drop-in API (bandsize 80, discretization 1): the reference-faithful defaults (fit on
+    the interpolated grid, the reference's theta initialiser) run and stay finite, and the documented deviation
+    ``hparam_fit_on="observed"`` lands on the right noise level."""
     import magi_v2
     g = np.load(os.path.join(GOLDEN, "g3_pipeline.npz"))
     model = magi_v2.MAGI_v2(D_thetas=3, ts_obs=g["seir3_ts_obs"], X_obs=g["seir3_X_obs"], bandsize=80, f_vec="seir3")
@@ -96,12 +148,5 @@ def test_vignette_end_to_end_with_fitted_hyperparameters():
     true_sd = 0.05 * np.ptp(g["rows"][:, 6:9], axis=0)
     assert np.all(np.abs(np.sqrt(model.sigma_sqs_init) / true_sd - 1.0) < 1.0)          # right order of magnitude
 
-    # parameter recovery is very sensitive to phi2 (measured: phi2 ~ 0.1 -> theta_0 ~ 1.5, phi2 ~ 1.1 -> 3.7,
-    # phi2 = 0.5 with the true noise level -> 5.96); with the latter the chain lands where the notebook's did
-    model.initial_fit(discretization=1, hparams={"phi2s": [0.5, 0.5, 0.5], "sigma_sqs": true_sd ** 2})
-    model.thetas_init = np.ones(3)
-    res = model.predict(num_results=300, num_burnin_steps=300, n_chains=4, seed=123)
-    th = res["thetas_samps"].reshape(-1, 3).mean(axis=0)
-    print("phi2", model.phi2s, "sigma", np.sqrt(model.sigma_sqs_init), "theta_mean", th)
-    assert abs(th[0] - 6.0) < 0.6 and abs(th[1] - 0.6) < 0.1 and abs(th[2] - 1.8) < 0.25, th
+    # (parameter recovery at the reference's length: the three tests above)
     model.engine.close()

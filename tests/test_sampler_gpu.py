@@ -92,13 +92,11 @@ def test_pause_resume_equals_single_run():
         np.testing.assert_array_equal(a, b)
 
 
-def test_chain_moves_toward_the_true_seir_parameters():
-    """Vignette configuration (SEIR-3, N=161, b=80; vignette.ipynb cells 5-8) at reduced length, four
-    chains from theta = (1, 1, 1).  The reference's own 1000+1000 run printed (5.831, 0.565, 1.77)
-    for the truth (6, 0.6, 1.8) (vignette.ipynb cell 11) -- with FITTED hyper-parameters (SURVEY 8 f1,
-    not built yet) and unseeded, so only a loose check is possible here: the chains must leave the
-    initial point in the right direction and stay finite.  Exact sampler behaviour is covered by the
-    draw-for-draw tests above."""
+def test_sampler_health_on_the_vignette_configuration():
+    """Vignette configuration (SEIR-3, N=161, b=80; vignette.ipynb cells 5-8) on the fixture's matrices, four chains from
+    theta = (1, 1, 1), 150 + 150 steps: the chains stay finite, accept at the adaptation target, do not diverge and keep X near
+    the data.  WHERE theta lands is asserted at the reference's own length (1000 + 1000) in tests/test_fit_gpu.py -- at this
+    length beta_temp is still ~0.2 and the mean is not meaningful; exact sampler behaviour is the draw-for-draw tests above."""
     g = load_g4("seir3_N161")
     pr = problem_from_g4(g, None)
     eng = engine_for(pr, 80)
@@ -109,14 +107,12 @@ def test_chain_moves_toward_the_true_seir_parameters():
     Xs, sp, tp = eng.sampler_samples()
     d = eng.sampler_diag()
     _, th = orc.transform_samples(sp, tp, pr.LB)
-    mean = th.reshape(-1, 3).mean(axis=0)
     eng.close()
     assert np.isfinite(Xs).all() and np.isfinite(th).all()
-    assert 3.0 < mean[0] < 8.0 and 0.1 < mean[1] < 1.2 and 0.8 < mean[2] < 2.8, mean
     assert d.has_divergence[:, 150:].mean() < 0.2
-    assert 0.5 < np.exp(np.minimum(d.log_accept_ratio[:, 150:], 0)).mean() <= 1.0
-    # X trajectories stay near the data they are conditioned on
+    assert 0.6 < np.exp(np.minimum(d.log_accept_ratio[:, 150:], 0)).mean() <= 0.9          # dual averaging targets 0.75
     assert np.abs(Xs.mean(axis=(0, 1)) - g["Xhat_init"]).max() < 0.1
+    assert th.reshape(-1, 3).mean(axis=0)[0] > 1.5                                           # beta has left theta_init = 1 upwards
 
 
 @pytest.mark.parametrize("L", [1, 7, 32])
