@@ -43,7 +43,7 @@ void free_matrices(magi_handle* h) {
 
 void free_chains(magi_handle* h) {
     DevChains& c = h->ch;
-    free_dev(c.vec); free_dev(c.ctl); free_dev(c.par); free_dev(c.plan); free_dev(c.part); free_dev(c.tpart); free_dev(c.opv); free_dev(c.gctl); free_dev(c.samples);
+    free_dev(c.vec); free_dev(c.ctl); free_dev(c.par); free_dev(c.plan); free_dev(c.part); free_dev(c.tpart); free_dev(c.xop); free_dev(c.gctl); free_dev(c.samples);
     free_dev(c.d_step_size); free_dev(c.d_lar); free_dev(c.d_target); free_dev(c.d_energy); free_dev(c.d_beta);
     free_dev(c.d_leapfrogs); free_dev(c.d_depth); free_dev(c.d_flags);
     free_dev(h->d_chain_ids); free_dev(h->d_fin);
@@ -127,9 +127,9 @@ int magi_ensure_chains(magi_handle* h, int n) {
         const size_t tpn = (size_t)n * 4 * h->pb.D * h->pb.nb * h->pb.Np;
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.tpart, sizeof(double) * tpn));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.tpart, 0, sizeof(double) * tpn));     // slots outside the block band stay zero
-        const size_t opn = (size_t)((n + 15) / 16) * 4 * h->pb.D * h->pb.Np * 16;
-        MAGI_HIP_CHECK(h, hipMalloc(&h->ch.opv, sizeof(double) * opn));
-        MAGI_HIP_CHECK(h, hipMemset(h->ch.opv, 0, sizeof(double) * opn));
+        const size_t opn = (size_t)2 * ((n + 15) / 16) * h->pb.D * h->pb.Np * 16;
+        MAGI_HIP_CHECK(h, hipMalloc(&h->ch.xop, sizeof(double) * opn));
+        MAGI_HIP_CHECK(h, hipMemset(h->ch.xop, 0, sizeof(double) * opn));
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.gctl, sizeof(GlobalCtl)));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.gctl, 0, sizeof(GlobalCtl)));
         MAGI_HIP_CHECK(h, hipMalloc(&h->d_chain_ids, sizeof(long long) * n));

@@ -296,104 +296,26 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
 //     column pair j)) for the row-type MFMAs; wave-private, so no barrier: LDS operations of one wave execute in order.
 // Wave w owns rows [32 w, 32 w + 32) of the block = 2 chunks of 16 rows x 4 column groups of 32: eight steps, a ring of
 // MC_RING steps' loads in flight.
-// The operand vectors xc = X - mu and f = drift(X, theta) of all chains are formed ONCE per slot by k_operands (each of the
-// 544 block workgroups gathering 16 chains x D components itself would move as many bytes as the operator blocks) in the
-// layout [xc | f][d][grid index][16 chains]: a block's column slice is one contiguous 16 KB piece (-> LDS), a wave's row slice
-// is read straight into the MFMA fragment registers.
+// The operand vectors xc = X - mu and f = drift(X, theta') are formed per workgroup from ch.xop, the mirror of the position
+// buffers in the order [d][grid index][16 chains] (kept by the point phase and the decisions): a block's slice of all 16 chains is
+// a contiguous, fully coalesced read -- gathering 16 chains x D components from the per-chain state vectors instead moved as
+// many L2 bytes as the operator blocks themselves.  theta' is derived per workgroup as in k_stream.
 constexpr int MC = 16;                                   // chain columns per pass
 constexpr int MC_PITCH = 34;                             // doubles per staged row: 32 columns + 2 (272 B: conflict-free transposed reads)
-constexpr int MC_SM_V = 0, MC_SM_ST = MC_SM_V + MAGI_TB * MC, MC_SM_CS = MC_SM_ST + 4 * 16 * MC_PITCH, MC_SM_DOUBLES = MC_SM_CS + MC * MAGI_TB;
+constexpr int MC_SM_V = 0, MC_SM_ST = MC_SM_V + MAGI_TB * MC, MC_SM_CS = MC_SM_ST + 4 * 16 * MC_PITCH, MC_SM_TH = MC_SM_CS + MC * MAGI_TB,
+              MC_SM_DOUBLES = MC_SM_TH + MC * 8;
 using mc_d4 = __attribute__((ext_vector_type(4))) double;
 #ifndef MAGI_MC_RING
 #define MAGI_MC_RING 5
 #endif
 constexpr int MC_RING = MAGI_MC_RING;                    // steps of tile loads in flight per wave (ring of register buffers)
 
-// sel: 0 = xc, 1 = f in row order [grid index][16 chains] (fragment order of the column-type MFMAs' chain operand);
-//      2 = xc, 3 = f in column-pair order [grid index / 2][16 chains][2] (the row-type MFMAs read two adjacent columns at once)
-__host__ __device__ inline size_t opv_off(const DevProblem& pb, int group, int sel, int d) {
-    return (((size_t)group * 4 + sel) * pb.D + d) * (size_t)pb.Np * MC;
-}
-
-// operand vectors of slot `parity` for every chain: what k_stream assumes per workgroup (the state the last plan leaves to be
-// evaluated; theta' derived from the point phase's partial sums with the decisions' own functions), once per chain and point.
-// grid (Np / 16, groups), 256 threads = (chain t & 15, point t >> 4).
-template <int DRIFT>
-__global__ __launch_bounds__(256) void k_operands(DevProblem pb, DevChains ch, int parity) {
-    using DR = DriftT<DRIFT>;
-    constexpr int D = DR::D, P = DR::P;
-    static_assert(P <= 8, "theta slots");
-    __shared__ double th_s[MC * 8];
-    const int all_done = ch.gctl->all_done;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lj = lane >> 4;
-    const int c0 = blockIdx.y * MC, nch = ch.n_chains;
-    {
-        double rows[4][P];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int cc = min(c0 + wave * 4 + k, nch - 1);
-            const double* part = ch.part + (size_t)cc * PART_K * ch.n_wg;
-#pragma unroll
-            for (int r = 0; r < P; ++r) rows[k][r] = (lane < ch.n_wg) ? part[(size_t)(PK_TP + r) * ch.n_wg + lane] : 0.0;
-            for (int w0 = 64; w0 < ch.n_wg; w0 += 64) {
-#pragma unroll
-                for (int r = 0; r < P; ++r) if (w0 + lane < ch.n_wg) rows[k][r] += part[(size_t)(PK_TP + r) * ch.n_wg + w0 + lane];
-            }
-        }
-        // this lane's own (chain 4 wave + lj, parameter li)
-        const int cc = min(c0 + wave * 4 + lj, nch - 1);
-        const LeafPlan* lp = ch.plan + (size_t)(parity ^ 1) * nch + cc;
-        const int lcur = lp->cur;
-        const double lhs = lp->hs, leps = lp->eps;
-        const bool lder = lp->active && !lp->skip && lp->leaf;
-        const int e = pb.ND + D + min(li, P - 1);
-        const double* vb = ch.vec + vec_off(pb, cc, 0);
-        const double qv = (vb + (size_t)(V_Q + lcur) * pb.dimp)[e], pv = (vb + (size_t)(V_P + lcur) * pb.dimp)[e];
-        const double parv = ch.par[(size_t)cc * PAR_COUNT + PAR_TH + min(li, P - 1)];
-        double tpp = 0.0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int r = 0; r < P; ++r) {
-                const double sres = wave_sum(rows[k][r]);
-                if (lj == k && li == r) tpp = sres;
-            }
-        double thp = parv;
-        if (lder && li < P) {
-            const double ex = m_exp(qv);
-            const double sg = ex / (1.0 + ex);                       // == par[PAR_SGT] of that state (compute_par_entry)
-            const double qnx = next_entry_pre(pv, qv, lhs, leps, theta_entry_grad(pb.beta_inv, tpp, sg));
-            thp = m_log(1.0 + m_exp(qnx));                           // == par'[PAR_TH] (compute_par_entry)
-        }
-        if (li < P) th_s[(wave * 4 + lj) * 8 + li] = thp;
-    }
-    if (all_done) return;
-    __syncthreads();
-    const int c = t & 15, cc = min(c0 + c, nch - 1), i = blockIdx.x * 16 + (t >> 4);
-    const LeafPlan* lp = ch.plan + (size_t)(parity ^ 1) * nch + cc;
-    const int buf = (lp->skip || !lp->leaf) ? lp->cur : (lp->cur ^ 1);
-    const double* q = ch.vec + vec_off(pb, cc, V_Q + buf);
-    const bool valid = (c0 + c < nch) && i < pb.N;
-    double x[D], th[P], f[D];
-#pragma unroll
-    for (int dd = 0; dd < D; ++dd) x[dd] = q[dd * pb.N + min(i, pb.N - 1)];
-#pragma unroll
-    for (int k = 0; k < P; ++k) th[k] = th_s[c * 8 + k];
-    DR::f(x, th, f);
-#pragma unroll
-    for (int dd = 0; dd < D; ++dd) {
-        const double xcv = valid ? x[dd] - pb.mu[dd] : 0.0, fv = valid ? f[dd] : 0.0;
-        ch.opv[opv_off(pb, blockIdx.y, 0, dd) + (size_t)i * MC + c] = xcv;
-        ch.opv[opv_off(pb, blockIdx.y, 1, dd) + (size_t)i * MC + c] = fv;
-        ch.opv[opv_off(pb, blockIdx.y, 2, dd) + ((size_t)(i >> 1) * MC + c) * 2 + (i & 1)] = xcv;
-        ch.opv[opv_off(pb, blockIdx.y, 3, dd) + ((size_t)(i >> 1) * MC + c) * 2 + (i & 1)] = fv;
-    }
-}
-
 template <int DRIFT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_stream_mc(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
-    constexpr int D = DriftT<DRIFT>::D, TB = MAGI_TB;
+    using DR = DriftT<DRIFT>;
+    constexpr int D = DR::D, P = DR::P, TB = MAGI_TB;
+    static_assert(P <= 8, "theta slots");
     const int all_done = ch.gctl->all_done;
     kernarg_prefetch<sizeof(DevProblem) + sizeof(DevChains) + sizeof(SamplerCfgDev) + sizeof(int)>();
     const int c0 = blockIdx.y * MC;
@@ -436,21 +358,101 @@ void k_stream_mc(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     for (int s = 0; s < MC_RING - 1; ++s)
 #pragma unroll
         for (int q = 0; q < 4; ++q) tl[s][q] = ld(s, q);
-    // operand slices (k_operands): columns of block column bj -> LDS (16 KB, copied as is); this wave's rows of block row bi ->
-    // fragment registers
-    const double2* vsrc = reinterpret_cast<const double2*>(ch.opv + opv_off(pb, blockIdx.y, kind == TK_FK ? 3 : 2, d) + (size_t)bj * TB * MC);
-    const double* wsrc = ch.opv + opv_off(pb, blockIdx.y, kind != TK_FH ? 1 : 0, d) + (size_t)(bi * TB + 32 * wave) * MC;
-    double2 vv[4];
+    // ---- theta' of every chain of the group (as k_stream: derived from the point phase's partial sums with the decisions' own
+    //      functions when the last plan was a leaf, else the state's parameter block).  Wave w: chains 4 w .. 4 w + 3, one per
+    //      16-lane row of the wave for the transcendental part.  Blocks of FH multiply xc on both sides and need none. ----
+    double* th_s = smem + MC_SM_TH;                                   // [chain][8]
+    if (kind != TK_FH) {
+        double rows[4][P];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) vv[k] = vsrc[(size_t)k * 256 + t];
-    double wf[2][4];                                                       // W[32 wave + 16 cidx + 4 q + lj][chain li]
+        for (int k = 0; k < 4; ++k) {
+            const int cc = min(c0 + wave * 4 + k, nch - 1);
+            const double* part = ch.part + (size_t)cc * PART_K * ch.n_wg;
 #pragma unroll
-    for (int cidx = 0; cidx < 2; ++cidx)
+            for (int r = 0; r < P; ++r) rows[k][r] = (lane < ch.n_wg) ? part[(size_t)(PK_TP + r) * ch.n_wg + lane] : 0.0;
+            for (int w0 = 64; w0 < ch.n_wg; w0 += 64) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wf[cidx][q] = wsrc[(size_t)(16 * cidx + 4 * q + lj) * MC + li];
+                for (int r = 0; r < P; ++r) if (w0 + lane < ch.n_wg) rows[k][r] += part[(size_t)(PK_TP + r) * ch.n_wg + w0 + lane];
+            }
+        }
+        const int cc = min(c0 + wave * 4 + lj, nch - 1);               // this lane's own (chain 4 wave + lj, parameter li)
+        const LeafPlan* lp = ch.plan + (size_t)(parity ^ 1) * nch + cc;
+        const int lcur = lp->cur;
+        const double lhs = lp->hs, leps = lp->eps;
+        const bool lder = lp->active && !lp->skip && lp->leaf;
+        const int e = pb.ND + D + min(li, P - 1);
+        const double* vb = ch.vec + vec_off(pb, cc, 0);
+        const double qv = (vb + (size_t)(V_Q + lcur) * pb.dimp)[e], pv = (vb + (size_t)(V_P + lcur) * pb.dimp)[e];
+        const double parv = ch.par[(size_t)cc * PAR_COUNT + PAR_TH + min(li, P - 1)];
+        double tpp = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < P; ++r) {
+                const double sres = wave_sum(rows[k][r]);
+                if (lj == k && li == r) tpp = sres;
+            }
+        double thp = parv;
+        if (lder && li < P) {
+            const double ex = m_exp(qv);
+            const double sg = ex / (1.0 + ex);                       // == par[PAR_SGT] of that state (compute_par_entry)
+            const double qnx = next_entry_pre(pv, qv, lhs, leps, theta_entry_grad(pb.beta_inv, tpp, sg));
+            thp = m_log(1.0 + m_exp(qnx));                           // == par'[PAR_TH] (compute_par_entry)
+        }
+        if (li < P) th_s[(wave * 4 + lj) * 8 + li] = thp;
+    }
     if (all_done) return;
+    __syncthreads();                 // th_s
+
+    // ---- operand slices from the operand-order mirror of the state each chain's last plan leaves to be evaluated ----
+    const double mud = MAGI_SEL_D(pb.mu, d);
+    auto operand = [&](const double* xb /* chain's buffer base + chain column */, int i, bool wantf, const double (&thv)[P]) -> double {
+        const size_t comp = (size_t)pb.Np * 16;
+        if (!wantf) return xb[(size_t)d * comp + (size_t)i * 16] - mud;
+        double x[D];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) reinterpret_cast<double2*>(smem + MC_SM_V)[k * 256 + t] = vv[k];
+        for (int dd = 0; dd < D; ++dd) x[dd] = xb[(size_t)dd * comp + (size_t)i * 16];
+        return DR::f1(d, x, thv);
+    };
+    {   // column slice of block column bj -> LDS, [column pair][chain]: thread = (chain t & 15, 4 of the 64 column pairs)
+        const int c = t & 15, cc = min(c0 + c, nch - 1);
+        const LeafPlan* lp = ch.plan + (size_t)(parity ^ 1) * nch + cc;
+        const int buf = (lp->skip || !lp->leaf) ? lp->cur : (lp->cur ^ 1);
+        const double* xb = ch.xop + xop_off(pb, nch, buf, cc, 0, 0);
+        const bool valid = c0 + c < nch, wantf = kind == TK_FK;
+        double thv[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) thv[k] = (kind != TK_FH) ? th_s[c * 8 + k] : 0.0;
+        double2 vv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cp = (t >> 4) + 16 * k, i0 = bj * TB + 2 * cp;
+            vv[k].x = (valid && i0 < pb.N) ? operand(xb, min(i0, pb.N - 1), wantf, thv) : 0.0;
+            vv[k].y = (valid && i0 + 1 < pb.N) ? operand(xb, min(i0 + 1, pb.N - 1), wantf, thv) : 0.0;
+            if (k & 1) __builtin_amdgcn_sched_barrier(0);          // (two column pairs' loads in flight at a time: more would not fit next to the tile ring)
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) reinterpret_cast<double2*>(smem + MC_SM_V)[((t >> 4) + 16 * k) * MC + c] = vv[k];
+    }
+    double wf[2][4];                                                   // W[32 wave + 16 cidx + 4 q + lj][chain li]: this wave's rows of block row bi
+    {
+        const int cc = min(c0 + li, nch - 1);
+        const LeafPlan* lp = ch.plan + (size_t)(parity ^ 1) * nch + cc;
+        const int buf = (lp->skip || !lp->leaf) ? lp->cur : (lp->cur ^ 1);
+        const double* xb = ch.xop + xop_off(pb, nch, buf, cc, 0, 0);
+        const bool valid = c0 + li < nch, wantf = kind != TK_FH;
+        double thv[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) thv[k] = (kind != TK_FH) ? th_s[li * 8 + k] : 0.0;
+#pragma unroll
+        for (int cidx = 0; cidx < 2; ++cidx)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = bi * TB + 32 * wave + 16 * cidx + 4 * q + lj;
+                wf[cidx][q] = (valid && i < pb.N) ? operand(xb, min(i, pb.N - 1), wantf, thv) : 0.0;
+                if (q == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+    }
     __syncthreads();                 // operand image complete
 
     const bool coltype = (kind == TK_FE) || (bi != bj);      // (diagonal blocks of FH / FK are stored full: complete by rows)
@@ -624,7 +626,6 @@ template <int DRIFT>
 int launch_stream_mc(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s) {
     const DevProblem& pb = h->pb;
     const int groups = (n_chains + MC - 1) / MC;
-    hipLaunchKernelGGL((k_operands<DRIFT>), dim3(pb.Np / 16, groups), dim3(256), 0, s, pb, h->ch, parity);
     static const int limit = [] { const char* e = getenv("MAGI_MC_LIMIT"); return e ? atoi(e) : 0; }();     // dev: time a truncated grid (wrong results)
     DevProblem pbl = pb;
     if (limit > 0 && limit < pb.n_tasks) pbl.n_tasks = limit;

@@ -100,7 +100,9 @@ struct GridPoint {     // component d of grid index i of one chain (one lane)
                 if (k < lp.nchk) { const double df = rs - o.crk[k]; pk[PK_DOT + 2 * k] = df * o.cpk[k]; pk[PK_DOT + 2 * k + 1] = df * pn; }
             const double pnext = pn + lp.hs * gx;
             *(vb + (size_t)(V_P + (lp.cur ^ 1)) * dimp + e) = pnext;
-            *(vb + (size_t)(V_Q + (lp.cur ^ 1)) * dimp + e) = xd + lp.eps * pnext;
+            const double xn = xd + lp.eps * pnext;
+            *(vb + (size_t)(V_Q + (lp.cur ^ 1)) * dimp + e) = xn;
+            if (ch.n_chains >= 3) ch.xop[xop_off(pb, ch.n_chains, lp.cur ^ 1, cc, d, i)] = xn;      // (three or more chains: the matrix-core stream reads this mirror)
         }
     }
 };

@@ -176,7 +176,8 @@ struct DevChains {
     double* part;         // [n_chains][PART_K][n_wg] partial sums of the point kernel
     int n_wg;             // workgroups along the grid axis of k_point
     double* tpart;        // [n_chains][4 (hx, ex, etf, kf)][D][nb][Np] block partials of the streaming kernel
-    double* opv;          // [ceil(n_chains / 16)][4 (xc, f: row order; xc, f: column-pair order)][D][Np][16] operand vectors of the matrix-core streaming kernel (leap.hip)
+    double* xop;          // [2 position buffers][ceil(n_chains / 16)][D][Np][16 chains]: mirror of the X part of V_Q / V_Q1 in the operand order of
+                          // the matrix-core streaming kernel (a block's slice of 16 chains is contiguous); kept by whoever writes those buffers
     double* par;          // [n_chains][PAR_COUNT] transformed parameters of the state in V_Q
     GlobalCtl* gctl;
     int n_chains;
@@ -191,6 +192,12 @@ struct DevChains {
     int* d_depth;
     int* d_flags;         // bit0 has_divergence, bit1 reach_max_depth, bit2 is_accepted
 };
+
+// element (buffer b, chain, component d, grid index i) of the operand-order mirror
+__host__ __device__ inline size_t xop_off(const DevProblem& pb, int n_chains, int b, int chain, int d, int i) {
+    const size_t groups = (size_t)((n_chains + 15) >> 4);
+    return ((((size_t)b * groups + (size_t)(chain >> 4)) * pb.D + d) * (size_t)pb.Np + i) * 16 + (chain & 15);
+}
 
 __host__ __device__ inline size_t vec_off(const DevProblem& pb, int chain, int slot) {
     return ((size_t)chain * V_COUNT + (size_t)slot) * (size_t)pb.dimp;

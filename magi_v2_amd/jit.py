@@ -4,64 +4,104 @@ The drift header emitted by magi_v2_amd.drift is written to ``jit_cache/<name>/u
 HIP sources are compiled with ``-DMAGI_USER_DRIFT_HEADER=...`` (hipcc, gfx950, one process per file).  Such a
 build instantiates the sampler's kernels for that drift alone, so it costs about a third of the base build;
 files that do not depend on the drift reuse the base build's objects.  Results are cached by content hash."""
+import fcntl
 import glob
 import hashlib
 import os
 import shutil
 import subprocess
+import tempfile
 
 from . import build as _build
 
-CACHE = os.path.join(_build.HERE, "jit_cache")
+# MAGI_JIT_CACHE relocates the cache (e.g. when the package directory is read-only)
+CACHE = os.environ.get("MAGI_JIT_CACHE") or os.path.join(_build.HERE, "jit_cache")
 _DRIFT_FREE = ("build.hip", "pack.hip")          # translation units without drift-dependent code
 
 
-def _source_digest() -> str:
+def _hipcc() -> str:
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _toolchain_digest() -> str:
+    """Sources + compiler version + extra flags: everything a cached library depends on besides the drift header."""
     h = hashlib.sha256()
     for f in sorted(_build.sources() + glob.glob(os.path.join(_build.CSRC, "*.h")) + [os.path.join(_build.HERE, "..", "include", "magi_hip.h")]):
         with open(f, "rb") as fh:
             h.update(fh.read())
+    try:
+        h.update(subprocess.run([_hipcc(), "--version"], capture_output=True, check=False).stdout)
+    except OSError:
+        pass
+    h.update(os.environ.get("MAGI_EXTRA_CFLAGS", "").encode())
     return h.hexdigest()[:12]
 
 
+def prune(keep_latest: int = 1) -> None:
+    """Explicit maintenance: per drift name keep the ``keep_latest`` most recently built libraries.  (library_for never deletes:
+    another process -- an older checkout sharing the cache -- may have a sibling build loaded.)"""
+    by_name = {}
+    for d in glob.glob(os.path.join(CACHE, "*_*")):
+        if os.path.isdir(d):
+            by_name.setdefault(os.path.basename(d).rsplit("_", 1)[0], []).append(d)
+    for dirs in by_name.values():
+        for d in sorted(dirs, key=os.path.getmtime, reverse=True)[keep_latest:]:
+            shutil.rmtree(d, ignore_errors=True)
+
+
 def library_for(drift, verbose: bool = False) -> str:
-    """Path of the specialised library for ``drift`` (a user Drift), building it if needed."""
+    """Path of the specialised library for ``drift`` (a user Drift), building it if needed.
+
+    Safe under concurrent callers (torchrun ranks, pytest-xdist workers constructing the same model): the check-build-publish
+    sequence holds an exclusive ``flock`` on a per-key lock file, objects are compiled in a private temporary directory and the
+    finished library is moved into place with one ``os.replace``."""
     if drift.header is None:
         raise ValueError("built-in drifts use the base library")
-    key = hashlib.sha256((drift.header + _source_digest()).encode()).hexdigest()[:16]
+    key = hashlib.sha256((drift.header + _toolchain_digest()).encode()).hexdigest()[:16]
     d = os.path.join(CACHE, f"{drift.name}_{key}")
     lib = os.path.join(d, "libmagi_hip_user.so")
     if os.path.exists(lib):
         return lib
-    for old in glob.glob(os.path.join(CACHE, f"{drift.name}_*")):      # builds of this drift against older sources
-        if old != d:
-            shutil.rmtree(old, ignore_errors=True)
     os.makedirs(d, exist_ok=True)
-    hdr = os.path.join(d, "user_drift.h")
-    with open(hdr, "w") as fh:
-        fh.write(drift.header)
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    wide = drift.D > 4 or drift.P > 6         # wider per-point lane groups / parameter blocks than the base build's
-    objs, procs = [], []
-    for src in _build.sources():
-        base = os.path.basename(src)
-        shared = os.path.join(_build.HERE, "build", base + ".o")
-        if base in _DRIFT_FREE and not wide and os.path.exists(shared) and not _build.needs_build():
-            objs.append(shared)
-            continue
-        obj = os.path.join(d, base + ".o")
-        objs.append(obj)
-        contract = [] if base == "build.hip" else ["-ffp-contract=on"]
-        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-function",
-               f'-DMAGI_USER_DRIFT_HEADER="{hdr}"'] + ((["-DMAGI_MAX_D=8"] if drift.D > 4 else []) + (["-DMAGI_MAX_P=8"] if drift.P > 6 else [])) + contract + ["-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for cmd, p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            raise RuntimeError("hipcc failed for the traced drift:\n" + out.decode(errors="replace")[-4000:])
-    tmp = lib + ".tmp"
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-Wl,-rpath,/opt/rocm/lib"])
-    os.replace(tmp, lib)
-    return lib
+    with open(os.path.join(d, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if os.path.exists(lib):                       # another process built it while we waited
+                return lib
+            hdr = os.path.join(d, "user_drift.h")
+            tmp_hdr = hdr + f".{os.getpid()}.tmp"
+            with open(tmp_hdr, "w") as fh:
+                fh.write(drift.header)
+            os.replace(tmp_hdr, hdr)
+            work = tempfile.mkdtemp(prefix="build_", dir=d)
+            try:
+                hipcc = _hipcc()
+                wide = drift.D > 4 or drift.P > 6         # wider per-point lane groups / parameter blocks than the base build's
+                objs, procs = [], []
+                for src in _build.sources():
+                    base = os.path.basename(src)
+                    shared = os.path.join(_build.HERE, "build", base + ".o")
+                    if base in _DRIFT_FREE and not wide and os.path.exists(shared) and not _build.needs_build():
+                        objs.append(shared)
+                        continue
+                    obj = os.path.join(work, base + ".o")
+                    objs.append(obj)
+                    contract = [] if base == "build.hip" else ["-ffp-contract=on"]
+                    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-function",
+                           f'-DMAGI_USER_DRIFT_HEADER="{hdr}"'] + ((["-DMAGI_MAX_D=8"] if drift.D > 4 else []) + (["-DMAGI_MAX_P=8"] if drift.P > 6 else [])) + \
+                        contract + os.environ.get("MAGI_EXTRA_CFLAGS", "").split() + ["-c", src, "-o", obj]
+                    if verbose:
+                        print(" ".join(cmd), flush=True)
+                    procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+                for cmd, p in procs:
+                    out, _ = p.communicate()
+                    if p.returncode != 0:
+                        raise RuntimeError("hipcc failed for the traced drift:\n" + out.decode(errors="replace")[-4000:])
+                tmp = os.path.join(work, "libmagi_hip_user.so")
+                subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-Wl,-rpath,/opt/rocm/lib"])
+                os.replace(tmp, lib)
+            finally:
+                shutil.rmtree(work, ignore_errors=True)
+            return lib
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)

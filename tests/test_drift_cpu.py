@@ -116,3 +116,25 @@ def test_transcendental_drifts_trace_through_numpy_ufuncs():
     for tok in ("exp(", "sqrt(", "tanh("):
         assert tok in d.header
     assert os.path.exists(jit.library_for(d))              # the emitted header compiles for gfx950
+
+
+def test_jit_library_for_is_safe_under_concurrent_callers(tmp_path, monkeypatch):
+    """torchrun ranks / xdist workers constructing the same model all call jit.library_for for the same key.  Four
+    processes race on an empty cache: exactly one compiles, all get the same finished library, no partial file is left."""
+    import multiprocessing as mp
+    import subprocess
+    import sys
+    cache = str(tmp_path / "jit")
+    code = ("import os, sys; os.environ['MAGI_JIT_CACHE'] = sys.argv[1]; sys.path.insert(0, sys.argv[2]);"
+            "from magi_v2_amd import drift, jit; from magi_v2_amd.drift_examples import EXAMPLES;"
+            "f, D, P = EXAMPLES['lotka_volterra']; print(jit.library_for(drift.resolve(f, D, P)))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, "-c", code, cache, root], stdout=subprocess.PIPE, stderr=subprocess.PIPE) for _ in range(4)]
+    outs = [p.communicate() for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1].decode()[-500:] for o in outs]
+    libs = {o[0].decode().strip().splitlines()[-1] for o in outs}
+    assert len(libs) == 1
+    lib = libs.pop()
+    assert os.path.exists(lib) and os.path.getsize(lib) > 100000
+    left = [f for f in os.listdir(os.path.dirname(lib)) if f.startswith("build_") or f.endswith(".tmp")]
+    assert left == [], left
