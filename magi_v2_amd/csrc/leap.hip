@@ -626,11 +626,8 @@ template <int DRIFT>
 int launch_stream_mc(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s) {
     const DevProblem& pb = h->pb;
     const int groups = (n_chains + MC - 1) / MC;
-    static const int limit = [] { const char* e = getenv("MAGI_MC_LIMIT"); return e ? atoi(e) : 0; }();     // dev: time a truncated grid (wrong results)
-    DevProblem pbl = pb;
-    if (limit > 0 && limit < pb.n_tasks) pbl.n_tasks = limit;
-    const dim3 grid(pbl.n_tasks + (with_decisions ? MC : 0), groups);
-    hipLaunchKernelGGL((k_stream_mc<DRIFT>), grid, dim3(256), 0, s, pbl, h->ch, h->cfg, parity);
+    const dim3 grid(pb.n_tasks + (with_decisions ? MC : 0), groups);
+    hipLaunchKernelGGL((k_stream_mc<DRIFT>), grid, dim3(256), 0, s, pb, h->ch, h->cfg, parity);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("stream (matrix-core) launch: ") + hipGetErrorString(e));
     return MAGI_OK;
