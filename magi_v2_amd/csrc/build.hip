@@ -789,6 +789,7 @@ struct Linalg {
     double* panel = nullptr;    // [batch][panel_elems]
     long bs_dinv = 0, bs_panel = 0;
     int* status = nullptr;      // [batch][2]
+    bool pooled = false;        // dinv / panel belong to the handle's work space
 };
 
 // optional per-class timing of the build (MAGI_BUILD_PROFILE=1): HIP events around every launch, so the
@@ -984,21 +985,30 @@ int lauum_tt(Linalg& la, const double* T, double* out, long bs_out) {
     return MAGI_OK;
 }
 
-int linalg_init(Linalg& la, magi_handle* h, int N, int batch = 1, long bsA = 0) {
-    la.h = h; la.s = h->stream; la.N = N; la.batch = batch; la.bsA = bsA;
+// pooled: dinv / panel come from the handle's grow-only work space (the matrix build) instead of fresh allocations
+int linalg_init(Linalg& la, magi_handle* h, int N, int batch = 1, long bsA = 0, bool pooled = false) {
+    la.h = h; la.s = h->stream; la.N = N; la.batch = batch; la.bsA = bsA; la.pooled = pooled;
     const int nb = (N + 127) / 128;
     la.bs_dinv = (long)nb * 128 * 128;
     la.bs_panel = (long)std::max((size_t)N * 128, (size_t)N * N / 2 + 128 * 128);
-    MAGI_HIP_CHECK(h, hipMalloc(&la.dinv, (size_t)la.bs_dinv * batch * sizeof(double)));
-    MAGI_HIP_CHECK(h, hipMalloc(&la.panel, (size_t)la.bs_panel * batch * sizeof(double)));
+    if (pooled) {
+        la.dinv = magi_workspace(h, magi_handle::WS_DINV, (size_t)la.bs_dinv * batch);
+        la.panel = magi_workspace(h, magi_handle::WS_PANEL, (size_t)la.bs_panel * batch);
+        if (!la.dinv || !la.panel) return MAGI_E_HIP;
+    } else {
+        MAGI_HIP_CHECK(h, hipMalloc(&la.dinv, (size_t)la.bs_dinv * batch * sizeof(double)));
+        MAGI_HIP_CHECK(h, hipMalloc(&la.panel, (size_t)la.bs_panel * batch * sizeof(double)));
+    }
     MAGI_HIP_CHECK(h, hipMalloc(&la.status, (size_t)2 * batch * sizeof(int)));
     MAGI_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_diag_chol_inv), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS_DOUBLES * (int)sizeof(double)));
     return MAGI_OK;
 }
 
 void linalg_free(Linalg& la) {
-    if (la.dinv) (void)hipFree(la.dinv);
-    if (la.panel) (void)hipFree(la.panel);
+    if (!la.pooled) {
+        if (la.dinv) (void)hipFree(la.dinv);
+        if (la.panel) (void)hipFree(la.panel);
+    }
     if (la.status) (void)hipFree(la.status);
     la.dinv = la.panel = nullptr; la.status = nullptr;
 }
@@ -1350,12 +1360,11 @@ int magi_build_dense_device(magi_handle* h, const double* I, int N, int D, int n
             B = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_sel, (free_b / 10 * 9) / per));
         if (getenv("MAGI_BUILD_SERIAL")) B = 1;
     }
-    DevBuf Kap, P, PP;
-    MAGI_HIP_CHECK(h, Kap.alloc(nn * B));
-    MAGI_HIP_CHECK(h, P.alloc(nn * B));
-    MAGI_HIP_CHECK(h, PP.alloc(nn * B));
+    struct { double* p; } Kap{magi_workspace(h, magi_handle::WS_KAP, nn * B)}, P{magi_workspace(h, magi_handle::WS_P, nn * B)},
+        PP{magi_workspace(h, magi_handle::WS_PP, nn * B)};
+    if (!Kap.p || !P.p || !PP.p) return MAGI_E_HIP;
     Linalg la{};
-    int rc = linalg_init(la, h, N, B, (long)nn);
+    int rc = linalg_init(la, h, N, B, (long)nn, true);
     std::vector<int> status((size_t)2 * n_sel, -1);
     for (int d0 = 0; d0 < n_sel && rc == MAGI_OK;) {
         int nb = 1;

@@ -35,6 +35,7 @@ void free_matrices(magi_handle* h) {
     free_dev(h->dTiles); free_dev(h->dTasks);
     for (int k = 0; k < 3; ++k) { free_dev(h->dDense[k]); h->dDense[k] = nullptr; }
     h->dense_N = h->dense_D = 0;
+    for (int k = 0; k < magi_handle::WS_COUNT; ++k) { free_dev(h->ws[k]); h->ws[k] = nullptr; h->ws_cap[k] = 0; }
     h->dCsym = h->dM = h->dMt = h->dKsym = h->dYobs = nullptr;
     h->dTiles = nullptr; h->dTasks = nullptr;
     h->tiles_cap = h->tasks_cap = 0;
@@ -106,6 +107,20 @@ int build_graph(magi_handle* h) {
 }
 
 }  // namespace
+
+double* magi_workspace(magi_handle* h, int k, size_t n) {
+    if (n <= h->ws_cap[k]) return h->ws[k];
+    if (h->ws[k]) (void)hipFree(h->ws[k]);
+    h->ws[k] = nullptr; h->ws_cap[k] = 0;
+    if (hipMalloc(&h->ws[k], n * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        h->ws[k] = nullptr;
+        magi_fail(h, MAGI_E_HIP, "work space allocation failed (" + std::to_string(n * sizeof(double) >> 20) + " MiB)");
+        return nullptr;
+    }
+    h->ws_cap[k] = n;
+    return h->ws[k];
+}
 
 int magi_ensure_chains(magi_handle* h, int n) {
     if (!h->have_matrices || !h->have_problem) return magi_fail(h, MAGI_E_STATE, "set matrices and problem first");

@@ -738,6 +738,11 @@ struct magi_handle {
     double* dTiles = nullptr;
     int* dTasks = nullptr;
     size_t tiles_cap = 0, tasks_cap = 0;
+    // work space of the matrix build and the packing, kept between calls (grow-only): a repeated build at N = 8192 otherwise spends
+    // more host time in hipMalloc / hipFree of ~35 GB than the GPU spends on the build
+    enum { WS_KAP = 0, WS_P, WS_PP, WS_DINV, WS_PANEL, WS_TCS, WS_TM, WS_TKS, WS_TE, WS_COUNT };
+    double* ws[WS_COUNT] = {};
+    size_t ws_cap[WS_COUNT] = {};
 
     // chains
     int n_chains = 0;
@@ -760,6 +765,9 @@ struct magi_handle {
     double* d_fin = nullptr;         // [cap_chains][8] finalize outputs
     size_t samples_cap = 0, diag_cap = 0;
 };
+
+// work-space slot `k` with room for n doubles (grow-only; freed by magi_destroy); nullptr + error on failure
+double* magi_workspace(magi_handle* h, int k, size_t n);
 
 // error helpers -------------------------------------------------------------------------------
 extern thread_local std::string g_magi_last_error;

@@ -160,11 +160,9 @@ int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double*
         }
         MAGI_HIP_CHECK(h, hipMemcpyAsync(h->dTasks, tasks.data(), tasks.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
         const size_t nn = (size_t)D * N * N;
-        double *tCs = nullptr, *tM = nullptr, *tKs = nullptr, *tE = nullptr;
-        MAGI_HIP_CHECK(h, hipMalloc(&tCs, nn * sizeof(double)));
-        MAGI_HIP_CHECK(h, hipMalloc(&tM, nn * sizeof(double)));
-        MAGI_HIP_CHECK(h, hipMalloc(&tKs, nn * sizeof(double)));
-        MAGI_HIP_CHECK(h, hipMalloc(&tE, nn * sizeof(double)));
+        double *tCs = magi_workspace(h, magi_handle::WS_TCS, nn), *tM = magi_workspace(h, magi_handle::WS_TM, nn),
+               *tKs = magi_workspace(h, magi_handle::WS_TKS, nn), *tE = magi_workspace(h, magi_handle::WS_TE, nn);
+        if (!tCs || !tM || !tKs || !tE) return MAGI_E_HIP;
         dim3 gd((N + 255) / 256, N, D);
         hipLaunchKernelGGL(k_pack<PACK_SYM>, gd, block, 0, h->stream, dC_inv, tCs, N, N, mask, 0);
         hipLaunchKernelGGL(k_pack<PACK_COPY>, gd, block, 0, h->stream, dM, tM, N, N, mask, 0);
@@ -175,7 +173,6 @@ int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double*
             e = hipGetLastError();
         }
         hipError_t se = hipStreamSynchronize(h->stream);     // (also keeps `tasks` alive until the copy is done)
-        (void)hipFree(tCs); (void)hipFree(tM); (void)hipFree(tKs); (void)hipFree(tE);
         if (rc) return rc;
         if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("fused pack launch: ") + hipGetErrorString(e));
         if (se != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("fused pack: ") + hipGetErrorString(se));
