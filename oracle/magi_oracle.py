@@ -13,6 +13,7 @@ Citations are relative to the reference tree (``/root/reference``):
 * temperature schedule + annealed kernel  ``magi_v2.py:833-835, 852-879``
 * sampler wiring ........................ ``magi_v2.py:360-371, 386-396``
 * host helpers .......................... ``magi_v2.py:475-498, 509-527, 552-556, 631-639, 695-770``
+* theta / unobserved-component initialisers ``magi_v2.py:133-179, 182-249``
 * drifts ................................ ``vignette.ipynb`` cell 3, ``test_magi_script.py:19-45``
 
 Pinning status
@@ -20,7 +21,11 @@ Pinning status
 * ``build_matrices`` / helpers: PINNED -- checked against outputs of the reference's own
   TF-free functions run in the build container (``tests/golden/make_golden.py`` ->
   ``tests/golden/*.npz``) and against 40-digit mpmath truth.
-* ``logpost``: pinned against an op-for-op torch transcription + autograd (fixture G4).
+* ``logpost``: pinned against an op-for-op torch transcription + autograd (fixture G4); that transcription is also a module
+  of its own, ``oracle/torch_cpu.py`` (the CPU baseline ``bench.py`` times), checked against G4 as well.
+* ``theta_init_objective`` / ``fit_thetas_init`` / ``fit_unobserved`` (``magi_v2.py:133-249``): restated line by line, checked
+  against an independent torch transcription + autograd and central differences; the optimiser is tf_keras Adam restated from
+  its documented defaults -- **parity unpinned** against tf_keras itself.
 * ``nuts_*`` / ``dual_averaging_*`` / ``sample_chain``: **PARITY UNPINNED**.  The arithmetic
   lives in tensorflow-probability 0.24.0 (``requirements.txt:8``), which is not in the
   reference tree and not installable here; the reference calls ``sample_chain`` without a
