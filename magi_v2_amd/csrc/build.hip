@@ -425,6 +425,64 @@ __device__ __forceinline__ void dg_tile_gemm(int K, FA a, FB b, double (&c)[2][2
     }
 }
 
+// One wave: acc (16 x 16, v_mfma_f64_16x16x4_f64 layout: lane holds rows (lane >> 4) + 4 r of column lane & 15) += sum over k < K of
+// a(m, k) * b(k, n) with the operands read from LDS through accessors (m, n = lane & 15; k = 4 step + (lane >> 4)).  K multiple of 4.
+template <class FA, class FB>
+__device__ __forceinline__ void dg_mfma(int K, FA a, FB b, d4& acc) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
+    for (int k = 0; k < K; k += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a(li, k + lj), b(k + lj, li), acc, 0, 0, 0);
+}
+
+// One wave: Cholesky factor of the 16 x 16 block of S at (b0, b0) and the inverse of that factor, in registers: lane r (& 15) holds
+// row r, pivots and multipliers travel by v_readlane (no barrier, no LDS in the loop).  L goes back to the lower triangle of the
+// block, X = L^-1 (lower) to the dense array X (pitch 33) at (x0, x0).  Returns the first non-positive pivot's index or -1 (uniform).
+__device__ __forceinline__ int dg_factor16(double* S, int b0, double* X, int x0) {
+    const int lane = threadIdx.x & 63, r = lane & 15;
+    double d[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) d[c] = S[(b0 + r) * DG_LD + b0 + c];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) if (c > r) d[c] = 0.0;              // (the upper part holds other data)
+    int fail = -1;
+    double myrd = 0.0;                                                   // lane k keeps 1 / L_kk
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double piv = readlane_f64(d[k], k);
+        if (!(piv > 0.0) && fail < 0) fail = b0 + k;                     // uniform; also catches NaN
+        // 1/sqrt(piv): v_rsq_f64 (~23 bits) + two Newton steps, then sqrt = piv * y with one correction (the library sqrt followed by a
+        // division is ~70 dependent fp64 instructions per column)
+        double y = __builtin_amdgcn_rsq(piv);
+        const double hp = 0.5 * piv;
+        y = fma(y, fma(-hp * y, y, 0.5), y);
+        y = fma(y, fma(-hp * y, y, 0.5), y);
+        double dk = piv * y;
+        dk = fma(fma(-dk, dk, piv), 0.5 * y, dk);
+        if (r == k) myrd = y;
+        d[k] = (r == k) ? dk : d[k] * y;
+#pragma unroll
+        for (int j = k + 1; j < 16; ++j) {
+            const double ljk = readlane_f64(d[k], j);
+            d[j] = fma(-d[k], ljk, d[j]);          // (rows r < j compute garbage in the upper triangle, which nothing reads: no predicate)
+        }
+    }
+    double x[16];                                                        // lane j holds column j of the inverse
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) sacc = fma(readlane_f64(d[k], i), x[k], sacc);
+        x[i] = (i < r) ? 0.0 : ((i == r) ? 1.0 : -sacc) * readlane_f64(myrd, i);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c <= r) S[(b0 + r) * DG_LD + b0 + c] = d[c];
+            X[(x0 + c) * 33 + x0 + r] = x[c];                            // X[c][r] (zero above the diagonal)
+        }
+    }
+    return fail;
+}
+
 #ifdef MAGI_DIAG_STAMPS      // dev: s_memtime at the phase boundaries of k_diag_chol_inv, printed by thread 0
 #define DG_STAMP(i) do { if (threadIdx.x == 0) dg_st[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define DG_STAMP_PRINT() do { if (threadIdx.x == 0 && block_row0 == 0) { printf("diag stamps (cycles from start):"); for (int q = 1; q < 16; ++q) printf(" %d:%lld", q, (long long)(dg_st[q] - dg_st[0])); printf("\n"); } } while (0)
@@ -449,19 +507,19 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) bad = -1;
     DG_STAMP(0);
-    // (eight unconditional loads in flight per thread, from clamped addresses: `S[..] = cond ? A[..] : pad` in a plain loop is a
-    //  load -> LDS store chain, one memory round trip per element)
-    for (int e0 = tid; e0 < 128 * 128; e0 += 256 * 8) {
-        double v[8];
+    // (32 loads in flight per thread -- two batches for the block -- and only the lower triangle is fetched: `S[..] = cond ? A[..] : pad`
+    //  in a plain loop is a load -> LDS store chain, one memory round trip per element; 8 per batch measured 17 k cycles of 290 k)
+    for (int e0 = tid; e0 < 128 * 128; e0 += 256 * 32) {
+        double v[32];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 32; ++u) {
             const int e = e0 + 256 * u, i = e >> 7, j = e & 127;
-            v[u] = A[(long)min(i, n - 1) * lda + min(j, n - 1)];
+            v[u] = (j <= i && i < n) ? A[(long)i * lda + j] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 32; ++u) {
             const int e = e0 + 256 * u, i = e >> 7, j = e & 127;
-            S[i * DG_LD + j] = (i < n && j < n) ? ((j <= i) ? v[u] : 0.0) : ((i == j) ? 1.0 : 0.0);      // identity padding
+            S[i * DG_LD + j] = (i < n && j < n) ? v[u] : ((i == j) ? 1.0 : 0.0);      // identity padding; zeros above the diagonal
         }
     }
     __syncthreads();
@@ -470,102 +528,81 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
 
     for (int kb = 0; kb < nsb; ++kb) {
         const int c0 = 32 * kb;
-        // ---- 1. diagonal sub-block: factor + inverse in the registers of wave 0 (lane = row, then lane = column) ----
+        // ---- 1. diagonal 32 x 32 sub-block by wave 0: two 16 x 16 register factorisations (dg_factor16) with the rank-16 update and the
+        //         off-diagonal block of the inverse between them on the matrix cores (wave-private: LDS operations of a wave are ordered).
+        //         T1 <- dense inv(L11) (32 x 32), then published as the transposed triangle + diagonal the rest of the kernel reads. ----
         if (wave == 0) {
-            const int r = lane & 31;
-            double d[32];
+            const int li = lane & 15, lj = lane >> 4, c1 = c0 + 16;
+            int fail = dg_factor16(S, c0, T1, 0);
+            {   // L21 = A21 X11a^T ; A22 -= L21 L21^T
+                d4 o = d4{0.0, 0.0, 0.0, 0.0};
+                dg_mfma(16, [&](int m, int k) { return S[(c1 + m) * DG_LD + c0 + k]; }, [&](int k, int n) { return T1[n * 33 + k]; }, o);
 #pragma unroll
-            for (int c = 0; c < 32; ++c) d[c] = S[(c0 + r) * DG_LD + c0 + c];          // (upper part holds zeros / inverse: masked below)
+                for (int r = 0; r < 4; ++r) S[(c1 + lj + 4 * r) * DG_LD + c0 + li] = o[r];
+                d4 u = d4{0.0, 0.0, 0.0, 0.0};
+                dg_mfma(16, [&](int m, int k) { return S[(c1 + m) * DG_LD + c0 + k]; }, [&](int k, int n) { return S[(c1 + n) * DG_LD + c0 + k]; }, u);
 #pragma unroll
-            for (int c = 0; c < 32; ++c) if (c > r) d[c] = 0.0;
-            int fail = -1;
-            double myrd = 0.0;                                                            // lane k keeps 1 / L_kk
-#pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                const double piv = readlane_f64(d[k], k);
-                if (!(piv > 0.0) && fail < 0) fail = c0 + k;                              // uniform; also catches NaN
-                // 1/sqrt(piv): v_rsq_f64 (~23 bits) + two Newton steps, then sqrt = piv * y with one correction.  The library
-                // sqrt followed by a division is ~70 dependent fp64 instructions per column, 60 % of this phase.
-                double y = __builtin_amdgcn_rsq(piv);
-                const double hp = 0.5 * piv;
-                y = fma(y, fma(-hp * y, y, 0.5), y);
-                y = fma(y, fma(-hp * y, y, 0.5), y);
-                double dk = piv * y;
-                dk = fma(fma(-dk, dk, piv), 0.5 * y, dk);
-                if (r == k) myrd = y;
-                d[k] = (r == k) ? dk : d[k] * y;
-#pragma unroll
-                for (int j = k + 1; j < 32; ++j) {
-                    const double ljk = readlane_f64(d[k], j);
-                    d[j] = fma(-d[k], ljk, d[j]);          // (rows r < j compute garbage in the upper triangle, which nothing reads: no predicate)
-                }
+                for (int r = 0; r < 4; ++r) S[(c1 + lj + 4 * r) * DG_LD + c1 + li] -= u[r];
             }
+            const int fail2 = dg_factor16(S, c1, T1, 16);
+            if (fail < 0) fail = fail2;
             if (fail >= 0 && lane == 0) bad = fail;
-            // inverse: lane j holds column j of inv(L11)
-            double x[32];
+            {   // X21 = -X22 (L21 X11a)
+                d4 tm = d4{0.0, 0.0, 0.0, 0.0};
+                dg_mfma(16, [&](int m, int k) { return S[(c1 + m) * DG_LD + c0 + k]; }, [&](int k, int n) { return T1[k * 33 + n]; }, tm);
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                double sacc = 0.0;
+                for (int r = 0; r < 4; ++r) T[(lj + 4 * r) * 33 + li] = tm[r];
+                d4 o = d4{0.0, 0.0, 0.0, 0.0};
+                dg_mfma(16, [&](int m, int k) { return T1[(16 + m) * 33 + 16 + k]; }, [&](int k, int n) { return T[k * 33 + n]; }, o);
 #pragma unroll
-                for (int k = 0; k < i; ++k) sacc = fma(readlane_f64(d[k], i), x[k], sacc);
-                x[i] = (i < r) ? 0.0 : ((i == r) ? 1.0 : -sacc) * readlane_f64(myrd, i);
+                for (int r = 0; r < 4; ++r) { T1[(16 + lj + 4 * r) * 33 + li] = -o[r]; T1[(lj + 4 * r) * 33 + 16 + li] = 0.0; }
             }
-            if (lane < 32) {
-#pragma unroll
-                for (int c = 0; c < 32; ++c) {
-                    if (c <= r) S[(c0 + r) * DG_LD + c0 + c] = d[c];                      // L11
-                    if (c > r) S[(c0 + r) * DG_LD + c0 + c] = x[c];                       // inv(L11)[c][r], stored transposed
-                }
-                double xr = 0.0;
-#pragma unroll
-                for (int c = 0; c < 32; ++c) if (c == r) xr = x[c];           // (a runtime index would put x[] in scratch)
-                dinv[c0 + r] = xr;
+            // publish: diagonal -> dinv, strict lower part of the inverse -> the upper triangle of S, transposed
+            for (int e = lane; e < 32 * 32; e += 64) {
+                const int c = e >> 5, k = e & 31;
+                const double v = T1[c * 33 + k];
+                if (k == c) dinv[c0 + c] = v;
+                else if (k < c) S[(c0 + k) * DG_LD + c0 + c] = v;
             }
         }
         __syncthreads();
         DG_STAMP(2 + 3 * kb);
         if (bad >= 0) break;
         if (kb == nsb - 1) break;
-        // ---- 2. rows below: L21 = A21 * inv(L11)^T, one thread per row ------------------------------------------------
-        {
-            const int i = c0 + 32 + tid;
-            if (i < nl) {
-                double a[32], o[32];
+        // ---- 2. rows below: L21 = A21 * inv(L11)^T on the matrix cores: 16-row tiles over the waves, both 16-column halves per tile ----
+        {   // (T1 holds the dense inv(L11) from step 1)
+            const int li = lane & 15, lj = lane >> 4;
+            for (int rt = wave; 16 * rt < nl - c0 - 32; rt += 4) {
+                const int i0 = c0 + 32 + 16 * rt;
+                d4 o0 = d4{0.0, 0.0, 0.0, 0.0}, o1 = d4{0.0, 0.0, 0.0, 0.0};
+                dg_mfma(32, [&](int m, int k) { return S[(i0 + m) * DG_LD + c0 + k]; }, [&](int k, int n) { return T1[n * 33 + k]; }, o0);
+                dg_mfma(32, [&](int m, int k) { return S[(i0 + m) * DG_LD + c0 + k]; }, [&](int k, int n) { return T1[(16 + n) * 33 + k]; }, o1);
+                // (the tile's rows are read by this wave only, and all its reads precede these writes: the MFMA results depend on them)
 #pragma unroll
-                for (int k = 0; k < 32; ++k) a[k] = S[i * DG_LD + c0 + k];
-#pragma unroll
-                for (int c = 0; c < 32; ++c) {
-                    double acc = a[c] * dinv[c0 + c];
-#pragma unroll
-                    for (int k = 0; k < c; ++k) acc = fma(a[k], S[(c0 + k) * DG_LD + c0 + c], acc);     // inv(L11)[c][k]
-                    o[c] = acc;
+                for (int r = 0; r < 4; ++r) {
+                    S[(i0 + lj + 4 * r) * DG_LD + c0 + li] = o0[r];
+                    S[(i0 + lj + 4 * r) * DG_LD + c0 + 16 + li] = o1[r];
                 }
-#pragma unroll
-                for (int c = 0; c < 32; ++c) S[i * DG_LD + c0 + c] = o[c];
             }
         }
         __syncthreads();
         DG_STAMP(3 + 3 * kb);
-        // ---- 3. trailing update A22 -= L21 L21^T on the lower triangle, 2 x 2 tiles ------------------------------------------
+        // ---- 3. trailing update A22 -= L21 L21^T on the lower 16 x 16 tiles (rank 32: 8 MFMAs per tile) ----
+        //         (a diagonal tile also writes its upper half: those entries belong to later diagonal sub-blocks' upper triangles,
+        //          which step 1 masks when it reads and overwrites with the inverse)
         {
-            const int m0 = c0 + 32, mt = (nl - m0) >> 1;           // tiles per side
-            for (int t = tid; t < mt * (mt + 1) / 2; t += 256) {           // lower tiles only: t = bi (bi + 1) / 2 + bj
-                int bi = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-                while (bi * (bi + 1) / 2 > t) --bi;
-                while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-                const int bj = t - bi * (bi + 1) / 2;
-                const int i = m0 + 2 * bi, j = m0 + 2 * bj;
-                double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
-#pragma unroll 8
-                for (int k = 0; k < 32; ++k) {
-                    const double a0 = S[i * DG_LD + c0 + k], a1 = S[(i + 1) * DG_LD + c0 + k];
-                    const double b0 = S[j * DG_LD + c0 + k], b1 = S[(j + 1) * DG_LD + c0 + k];
-                    c00 = fma(a0, b0, c00); c01 = fma(a0, b1, c01); c10 = fma(a1, b0, c10); c11 = fma(a1, b1, c11);
-                }
-                S[i * DG_LD + j] -= c00;
-                S[(i + 1) * DG_LD + j] -= c10;
-                S[(i + 1) * DG_LD + j + 1] -= c11;
-                if (bj < bi) S[i * DG_LD + j + 1] -= c01;           // (on the diagonal tile that entry is in the upper triangle)
+            const int li = lane & 15, lj = lane >> 4;
+            const int m0 = c0 + 32, mt = (nl - m0) >> 4;           // 16-tiles per side
+            for (int t = wave; t < mt * (mt + 1) / 2; t += 4) {    // t = I (I + 1) / 2 + J
+                int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                while (I * (I + 1) / 2 > t) --I;
+                while ((I + 1) * (I + 2) / 2 <= t) ++I;
+                const int J = t - I * (I + 1) / 2;
+                const int i0 = m0 + 16 * I, j0 = m0 + 16 * J;
+                d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+                dg_mfma(32, [&](int m, int k) { return S[(i0 + m) * DG_LD + c0 + k]; }, [&](int k, int n) { return S[(j0 + n) * DG_LD + c0 + k]; }, acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[(i0 + lj + 4 * r) * DG_LD + j0 + li] -= acc[r];
             }
         }
         __syncthreads();
@@ -579,42 +616,43 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
     auto Xf = [&](int i, int j) -> double { return i == j ? dinv[i] : (i > j ? S[j * DG_LD + i] : 0.0); };
     for (int bi = 1; bi < nsb; ++bi)
         for (int bj = 0; bj < bi; ++bj) {
-            double c[2][2];
-            // the diagonal blocks X_jj, X_ii live as a transposed triangle + a separate diagonal (Xf): dense copies, so that the
-            // product loops below are plain LDS reads the compiler can keep eight deep in flight
+            // the diagonal blocks X_jj, X_ii live as a transposed triangle + a separate diagonal (Xf): dense copies for the MFMA operands
             for (int e = tid; e < 32 * 32; e += 256) {
                 const int i = e >> 5, j = e & 31;
                 T1[i * 33 + j] = Xf(32 * bj + i, 32 * bj + j);
                 T2[i * 33 + j] = Xf(32 * bi + i, 32 * bi + j);
             }
             __syncthreads();
-            dg_tile_gemm(32,
-                         [&](int i, int k) { return S[(32 * bi + i) * DG_LD + 32 * bj + k]; },
-                         [&](int k, int j) { return T1[k * 33 + j]; }, c);
-            dg_tile_gemm((bi - bj - 1) * 32,
-                         [&](int i, int k) { return S[(32 * bi + i) * DG_LD + 32 * bj + 32 + k]; },
-                         [&](int k, int j) { return S[(32 * bj + j) * DG_LD + 32 * bj + 32 + k]; }, c, true);
-            const int ti = (tid >> 4) * 2, tj = (tid & 15) * 2;
-            T[ti * 33 + tj] = c[0][0]; T[ti * 33 + tj + 1] = c[0][1]; T[(ti + 1) * 33 + tj] = c[1][0]; T[(ti + 1) * 33 + tj + 1] = c[1][1];
+            // wave = 16 x 16 quarter (ti, tj) of the 32 x 32 block
+            const int li = lane & 15, lj = lane >> 4, ti = 16 * (wave >> 1), tj = 16 * (wave & 1);
+            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+            dg_mfma(32, [&](int m, int k) { return S[(32 * bi + ti + m) * DG_LD + 32 * bj + k]; },
+                    [&](int k, int n) { return T1[k * 33 + tj + n]; }, acc);
+            dg_mfma((bi - bj - 1) * 32, [&](int m, int k) { return S[(32 * bi + ti + m) * DG_LD + 32 * bj + 32 + k]; },
+                    [&](int k, int n) { return S[(32 * bj + tj + n) * DG_LD + 32 * bj + 32 + k]; }, acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[(ti + lj + 4 * r) * 33 + tj + li] = acc[r];
             __syncthreads();
-            dg_tile_gemm(32,
-                         [&](int i, int k) { return T2[i * 33 + k]; },
-                         [&](int k, int j) { return T[k * 33 + j]; }, c);
-            __syncthreads();                       // every thread is done with T and with the X blocks it read
-            S[(32 * bj + tj) * DG_LD + 32 * bi + ti] = -c[0][0];
-            S[(32 * bj + tj + 1) * DG_LD + 32 * bi + ti] = -c[0][1];
-            S[(32 * bj + tj) * DG_LD + 32 * bi + ti + 1] = -c[1][0];
-            S[(32 * bj + tj + 1) * DG_LD + 32 * bi + ti + 1] = -c[1][1];
+            d4 out = d4{0.0, 0.0, 0.0, 0.0};
+            dg_mfma(32, [&](int m, int k) { return T2[(ti + m) * 33 + k]; }, [&](int k, int n) { return T[k * 33 + tj + n]; }, out);
+            __syncthreads();                       // every wave is done with T and with the X blocks it read
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(32 * bj + tj + li) * DG_LD + 32 * bi + ti + lj + 4 * r] = -out[r];      // X_ij[ti + row][tj + col], stored transposed
             __syncthreads();
         }
     DG_STAMP(14);
+    // L back into the block (lower triangle; zeros above it) and the dense inverse: eight elements' LDS reads in flight per thread
+#pragma unroll 8
     for (int e = tid; e < 128 * 128; e += 256) {
         const int i = e >> 7, j = e & 127;
-        if (i < n && j < n) A[(long)i * lda + j] = (j <= i) ? S[i * DG_LD + j] : 0.0;
+        const double v = S[i * DG_LD + j];
+        if (i < n && j < n) A[(long)i * lda + j] = (j <= i) ? v : 0.0;
     }
+#pragma unroll 8
     for (int e = tid; e < 128 * 128; e += 256) {
         const int i = e >> 7, j = e & 127;
-        Linv[e] = (i < n && j <= i) ? (i == j ? dinv[i] : S[j * DG_LD + i]) : 0.0;
+        const double v = S[min(j, i) * DG_LD + max(j, i)], dv = dinv[i];
+        Linv[e] = (i < n && j <= i) ? (i == j ? dv : v) : 0.0;
     }
     DG_STAMP(15);
     DG_STAMP_PRINT();
