@@ -186,3 +186,23 @@ def test_seven_parameter_system_chain_matches_oracle():
     np.testing.assert_allclose(tp[0], otp, rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(Xs[0], oX, rtol=0, atol=1e-8 * np.abs(oX).max())
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["ptrans", "competition7", "fhn"])
+def test_user_drift_batched_states_on_the_matrix_core_kernel(name):
+    """Three or more states per call take the matrix-core streaming kernel (k_stream_mc); for a traced drift with 5 components /
+    7 parameters that is the library built with the wider lane groups.  Batched fused == batched three-phase == per-state oracle."""
+    eng, pr, Xhat, hp, truth = make_problem(name)
+    rng = np.random.default_rng(11)
+    D, P, n = Xhat.shape[1], len(truth), 5
+    X = Xhat[None] + rng.normal(0, 0.05, (n,) + Xhat.shape)
+    sp, tp = rng.normal(-3, 0.5, (n, D)), np.log(np.expm1(truth))[None] + rng.normal(0, 0.2, (n, P))
+    a = eng.logpost_grad(X, sp, tp, 0.7)
+    b = eng.logpost_grad(X, sp, tp, 0.7, fused=True)
+    for c in range(n):
+        L, gX, gs, gt = orc.logpost_grad(X[c], sp[c], tp[c], 0.7, pr)
+        for out in (a, b):
+            assert abs(out[0][c] - L) <= 1e-9 * abs(L)
+            np.testing.assert_allclose(out[1][c], gX, rtol=0, atol=1e-9 * np.abs(gX).max())
+            np.testing.assert_allclose(out[3][c], gt, rtol=1e-8, atol=1e-9 * np.abs(gX).max())
+    eng.close()
