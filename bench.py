@@ -8,8 +8,8 @@ grid points (dt = 0.025, observations at even indices, noise 0.05 * range, PCG64
 matrices, hyper-parameters at the reference's starting values, theta_init = (1, 1, 1), NUTS (max
 tree depth 10) with dual averaging and the logarithmic annealing schedule -- i.e. the reference's
 predict() sampler (magi_v2.py:357-396) -- one chain per GPU.  A "step" is one NUTS transition of
-every chain on the rank.  Setup (data, GPU matrix build, burn-in/adaptation) is untimed; the timed
-region is exactly K transitions with all inputs resident in HBM.
+every chain on the rank.  Setup (data, GPU matrix build, 400 burn-in transitions that adapt the step size) is
+untimed; the timed region is exactly K transitions with all inputs resident in HBM.
 
 One rank per GPU (torchrun); chains are independent (no data-path collective); the post-burn-in
 samples of all ranks are gathered once to rank 0 over RCCL after the timed region.
@@ -37,7 +37,11 @@ def parse():
     ap.add_argument("--chains-per-gpu", type=int, default=1,
                     help="chains sampled on every GPU.  1 = BASELINE config 2 (the N=1 headline); 8 = config 3 "
                          "(64 independent chains over 8 GPUs): python -m torch.distributed.run ... bench.py --gpus 8 --chains-per-gpu 8")
-    ap.add_argument("--burnin", type=int, default=40, help="untimed adaptation steps before warmup")
+    ap.add_argument("--burnin", type=int, default=400,
+                    help="untimed burn-in transitions before warmup (80 %% of them adapt the step size, magi_v2.py:365).  400: the dual-averaging "
+                         "step size has flattened by then (1.3e-3 after 40 steps, 2.1e-3 after 100, 2.5e-3 after 200, 2.8e-3 after 400 on this "
+                         "workload), i.e. the timed transitions are those of an adapted sampler; with 40 (round 1) the trees of most chains are "
+                         "twice as long as in steady state and the spread between chains is 1.5x (DESIGN.md section 5)")
     ap.add_argument("--band", type=int, default=-1, help="bandsize (-1 = dense)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2, help="oracle NUTS transitions for the CPU baseline")
@@ -148,6 +152,21 @@ def main():
     post = diag.tree_depth[:, a.burnin + a.warmup:]
 
     state = eng.sampler_state() if (world == 1 and not a.no_cpu_baseline) else None   # before the timing launches clobber it
+
+    # ---- the same chains under round 1's protocol (40 untimed burn-in transitions): continuity with BENCH_r01 ----
+    r1 = None
+    if a.burnin != 40:
+        c40 = eng.default_cfg(num_results=a.warmup + a.steps, num_burnin_steps=40, stale_cache=0)
+        eng.sampler_init(c40, rep(Xhat), rep(sig_pre0), rep(th_pre0), seed=a.seed, chain_ids=chain_ids)
+        eng.sampler_run(40 + a.warmup)
+        torch.cuda.synchronize()
+        tr0 = time.perf_counter()
+        rlf, _ = eng.sampler_run(a.steps)
+        torch.cuda.synchronize()
+        r1s = time.perf_counter() - tr0
+        r1 = {"burnin_untimed": 40, "samples_per_s": round(cpg * a.steps / r1s, 2), "leapfrogs_per_s": round(rlf / r1s, 1),
+              "leapfrogs_per_sample": round(rlf / (cpg * a.steps), 1), "scope": "rank 0",
+              "note": "after 40 steps dual averaging is still ramping (step size about half its adapted value): not the sampler's steady state"}
 
     # ---- fixed-L HMC (L = 32, step size from a 100-step dual-averaging warm-up), SURVEY 8d: reported next to NUTS ----
     hcfg = eng.default_cfg(num_results=a.steps, num_burnin_steps=100, stale_cache=0, mode=1, hmc_leapfrogs=32)
@@ -269,7 +288,10 @@ def main():
         "config": {"workload": f"SEIR N={N} x 4 components, {'dense' if band is None else 'band ' + str(band)}, "
                                f"NUTS(max depth 10)+dual averaging+log annealing, {cpg} chain(s)/GPU",
                    "grid": N, "components": D, "thetas": P, "chains_total": n_chains, "bandsize": band,
-                   "burnin_untimed": a.burnin, "parallelism": f"chains x{world}",
+                   "burnin_untimed": a.burnin,
+                   "burnin_note": "untimed transitions that adapt the step size before the timed region (the reference burns in 1000); "
+                                  "round 1 used 40, see round1_protocol for that figure on the same chains and DESIGN.md section 5",
+                   "parallelism": f"chains x{world}",
                    "stale_cache": 0, "stale_cache_note": "the reference's annealed kernel reuses the previous step's cached target (computed at the "
                                    "previous temperature); on this synthetic grid that offset rejects every proposal, so the bench recomputes at "
                                    "the current temperature -- same arithmetic per leapfrog (DESIGN.md 4.2)",
@@ -278,7 +300,8 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu,
         "leapfrogs_per_s": round(lf_total / elapsed, 1), "us_per_leapfrog_slot": round(elapsed / (lf_total / n_chains) * 1e6, 2),
         "mean_tree_depth": round(float(post.mean()), 2), "device_ms": round(dev_ms, 2), "build_ms": round(build_ms, 1),
-        "gather_ms": round(gather_ms, 3), "hmc_L32": hmc, "theta_mean": [round(float(x), 4) for x in np.log1p(np.exp(th_all)).reshape(-1, P).mean(axis=0)],
+        "leapfrogs_per_sample": round(lf_total / (n_chains * a.steps), 1),
+        "gather_ms": round(gather_ms, 3), "hmc_L32": hmc, "round1_protocol": r1, "theta_mean": [round(float(x), 4) for x in np.log1p(np.exp(th_all)).reshape(-1, P).mean(axis=0)],
     }
     if cpu:
         out["speedup_vs_cpu_port"] = round(value / cpu["value"], 1)          # against the BEST thread count of the torch-CPU leg

@@ -13,12 +13,12 @@ sp, tp = host.softplus_inverse_inits(hp["sigma_sqs"], np.ones(3), LB)
 eng = MagiEngine(0)
 eng.build_matrices(I, hp["phi1s"], hp["phi2s"], 2.01, want_host=False)
 eng.set_problem(Xi.mean(axis=0), N_ds.astype(float), idx, y, beta, LB, "seir4")
-for burn in (40, 150):
+for burn in (40, 100, 200, 400):
     out = []
     for cid in range(8):
-        cfg = eng.default_cfg(num_results=23, num_burnin_steps=burn, stale_cache=0)
+        cfg = eng.default_cfg(num_results=25, num_burnin_steps=burn, stale_cache=0)
         eng.sampler_init(cfg, Xhat, sp, tp, seed=20250103, chain_ids=[cid])
-        eng.sampler_run(burn + 3)
+        eng.sampler_run(burn + 5)
         t0 = time.perf_counter(); lf, ms = eng.sampler_run(20); dt = time.perf_counter() - t0
         d = eng.sampler_diag()
         out.append((dt * 1e3 / 20, lf / 20, d.step_size[0, -1]))
