@@ -22,4 +22,12 @@ MAGI_BUILD_PROFILE=1 timeout -k 10 200 python3 tools/exp_build_profile.py 8192 >
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $O/pmc_gemm -- python3 tools/exp_build_once.py 8192 > $O/pmc_gemm.log 2>&1 || exit 1
 # 5. micro
 timeout -k 5 60 tools/micro/readshape > $O/micro_readshape.txt 2>&1
+# 6. summaries on the box; the raw per-launch csv files (tens of MB) stay behind: gpurun returns at most 64 MiB
+python3 tools/pmc_summary.py $O/pmc_traffic_summary.csv $O/pmc_fetch $O/pmc_write > /dev/null
+python3 tools/pmc_summary.py $O/pmc_l2_summary.csv $O/pmc_l2 > /dev/null
+python3 tools/pmc_summary.py $O/pmc_gemm_summary.csv $O/pmc_gemm > /dev/null
+python3 tools/trace_summary.py $(ls $O/kt_graph2/*/*kernel_trace.csv | head -1) > $O/kt_graph2_summary.txt
+find $O -name "*kernel_trace.csv" -delete
+find $O -name "*counter_collection.csv" -delete
+du -sh $O
 echo COLLECTED
