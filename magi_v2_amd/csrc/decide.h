@@ -450,7 +450,7 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
                     pw[e] = ph;
                     const double qn = q0[u] + eps * ph;
                     qw[e] = qn;
-                    if (ch.n_chains >= 3 && e < pb.ND) { const int dd = e / pb.N; ch.xop[xop_off(pb, ch.n_chains, c.cur, chain, dd, e - dd * pb.N)] = qn; }
+                    if (ch.n_chains >= 3 && e < pb.ND) { const int dd = e / pb.N; ch.xop[xop_off(pb, ch.n_chains, parity ^ 1, chain, dd, e - dd * pb.N)] = qn; }   // (read by the next slot's stream)
                     v.rhosub[e] = 0.0;
                     if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par, true, s_cst + MAGI_MAX_D);
                 }

@@ -296,20 +296,27 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
 //     column pair j)) for the row-type MFMAs; wave-private, so no barrier: LDS operations of one wave execute in order.
 // Wave w owns rows [32 w, 32 w + 32) of the block = 2 chunks of 16 rows x 4 column groups of 32: eight steps, a ring of
 // MC_RING steps' loads in flight.
-// The operand vectors xc = X - mu and f = drift(X, theta') are formed per workgroup from ch.xop, the mirror of the position
-// buffers in the order [d][grid index][16 chains] (kept by the point phase and the decisions): a block's slice of all 16 chains is
-// a contiguous, fully coalesced read -- gathering 16 chains x D components from the per-chain state vectors instead moved as
-// many L2 bytes as the operator blocks themselves.  theta' is derived per workgroup as in k_stream.
+// The operand vectors xc = X - mu and f = drift(X, theta') are formed per workgroup from ch.xop, the mirror of the positions a
+// slot evaluates in the order [slot parity][d][grid index][8 or 16 chains] (written by the point phase and the decisions of the
+// slot before): a block's slice of all chains is a contiguous, fully coalesced read found without a plan look-up -- gathering 16
+// chains x D components from the per-chain state vectors instead moved as many L2 bytes as the operator blocks themselves.
+// theta' is derived per workgroup as in k_stream.
 constexpr int MC = 16;                                   // chain columns per pass
 constexpr int MC_PITCH = 34;                             // doubles per staged row: 32 columns + 2 (272 B: conflict-free transposed reads)
 constexpr int MC_SM_V = 0, MC_SM_ST = MC_SM_V + MAGI_TB * MC, MC_SM_CS = MC_SM_ST + 4 * 16 * MC_PITCH, MC_SM_TH = MC_SM_CS + MC * MAGI_TB,
               MC_SM_DOUBLES = MC_SM_TH + MC * 8;
 using mc_d4 = __attribute__((ext_vector_type(4))) double;
 #ifndef MAGI_MC_RING
-#define MAGI_MC_RING 5
+#define MAGI_MC_RING 3
 #endif
-constexpr int MC_RING = MAGI_MC_RING;                    // steps of tile loads in flight per wave (ring of register buffers)
+constexpr int MC_RING = MAGI_MC_RING;                    // steps of tile loads in flight per wave + 1 (ring of register buffers; 3: 22.7 us, 4: 23.2, 5: 23.6 at 8 chains)
 
+#ifdef MAGI_MC_STAMPS      // dev: 100 MHz time stamps of ONE stream workgroup (task MAGI_MC_STAMPS) into par[40 ..] of chain 0 (tools/exp_mc_stamps.py)
+#define MC_STAMP(i) do { if ((int)blockIdx.x - n_dec == (MAGI_MC_STAMPS) && blockIdx.y == 0 && threadIdx.x == 0) \
+    reinterpret_cast<unsigned long long*>(ch.par + 40)[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MC_STAMP(i) do { } while (0)
+#endif
 template <int DRIFT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_stream_mc(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
@@ -341,6 +348,7 @@ void k_stream_mc(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     const int li = lane & 15, lj = lane >> 4;
     double* stage = smem + MC_SM_ST + wave * 16 * MC_PITCH;
     const int tix = (int)blockIdx.x - n_dec;
+    MC_STAMP(0);
     typedef const int __attribute__((address_space(4))) * const_int_ptr;
     const_int_ptr tk = (const_int_ptr)(unsigned long long)(pb.tasks + 4 * (size_t)tix);
     const int d = tk[0], kind = tk[1], bi = tk[2], bj = tk[3];
@@ -354,108 +362,180 @@ void k_stream_mc(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     const double2* A = reinterpret_cast<const double2*>(pb.tiles + (size_t)tix * TB * TB) + (size_t)(32 * wave + lj) * (TB / 2) + li;
     auto ld = [&](int s, int q) { return A[(size_t)(16 * (s & 1) + 4 * q) * (TB / 2) + 16 * ((wave + (s >> 1)) & 3)]; };
     double2 tl[MC_RING][4];
-#pragma unroll
-    for (int s = 0; s < MC_RING - 1; ++s)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) tl[s][q] = ld(s, q);
-    // ---- theta' of every chain of the group (as k_stream: derived from the point phase's partial sums with the decisions' own
-    //      functions when the last plan was a leaf, else the state's parameter block).  Wave w: chains 4 w .. 4 w + 3, one per
-    //      16-lane row of the wave for the transcendental part.  Blocks of FH multiply xc on both sides and need none. ----
+    const bool coltype = (kind == TK_FE) || (bi != bj);      // (diagonal blocks of FH / FK are stored full: complete by rows)
+    const bool colf = kind == TK_FK, rowf = kind != TK_FH;   // which operand slices are drift values (else xc = x - mu)
+    MC_STAMP(13);
+
+    // Order of the prologue's loads.  Every workgroup of the grid starts at about the same time, and once the tile loads are out
+    // (tens of MB across the device) anything issued behind them -- by anyone -- queues for microseconds; a wave's loads also
+    // complete in order.  Measured with the tile ring issued first: theta' 4.7 us, operands 5.4 us, first MFMA 10 us after the
+    // workgroup's start, half of its life.  So everything the operands depend on is issued FIRST, in one round with no dependent
+    // address: the inputs of theta' (the parameter entries of BOTH position buffers: which one counts is in the plan, fetched in
+    // the same round), the plans' `active` bits, and the raw positions of both operand slices from the operand-order mirror --
+    // which is indexed by SLOT PARITY (whoever sets up the state a slot evaluates writes xop[that slot & 1]), not by the
+    // ping-pong buffer the plan names.  The tile ring goes out behind them.
+    // ---- (1) inputs of theta' (as k_stream: derived from the point phase's partial sums with the decisions' own functions when
+    //      the last plan was a leaf, else the state's parameter block).  Wave w: chains 4 w .. 4 w + 3, one per 16-lane row of
+    //      the wave for the transcendental part.  Blocks of FH multiply xc on both sides and need none. ----
     double* th_s = smem + MC_SM_TH;                                   // [chain][8]
+    // (The prologue is instruction-bound, not latency-bound: 1 400 instructions per wave in its first version -- 64-bit address
+    //  arithmetic per load, an exec-mask region per element -- took 3.5 us to ISSUE on a CU that runs twelve such waves.  Hence:
+    //  wave-uniform bases + 32-bit byte offsets, the uniform cases hoisted out of the loops, the group's chains spread over the
+    //  four waves for theta'.)
+    const int ngrp = min(nch - c0, MC), kpw = (ngrp + 3) >> 2;       // chains of this group; chains per wave for theta'
+    auto ldb = [](const double* sbase, unsigned boff) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(sbase) + boff); };
+    double rows[4][P];
+    int lcur = 0; double lhs = 0.0, leps = 0.0, qv0 = 0.0, qv1 = 0.0, pv0 = 0.0, pv1 = 0.0, parv = 0.0; bool lder = false;
+    const int cg = wave * kpw + lj;                                    // this lane's own (chain cg of the group, parameter li)
+    const bool mine = lj < kpw && cg < ngrp && li < P;
     if (kind != TK_FH) {
-        double rows[4][P];
+        const unsigned lo8 = (unsigned)min(lane, ch.n_wg - 1) * 8u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int cc = min(c0 + wave * 4 + k, nch - 1);
-            const double* part = ch.part + (size_t)cc * PART_K * ch.n_wg;
+            if (k < kpw) {
+                const double* part = ch.part + ((size_t)min(c0 + wave * kpw + k, nch - 1) * PART_K + PK_TP) * ch.n_wg;      // (wave-uniform)
 #pragma unroll
-            for (int r = 0; r < P; ++r) rows[k][r] = (lane < ch.n_wg) ? part[(size_t)(PK_TP + r) * ch.n_wg + lane] : 0.0;
-            for (int w0 = 64; w0 < ch.n_wg; w0 += 64) {
+                for (int r = 0; r < P; ++r) { const double v = ldb(part + (size_t)r * ch.n_wg, lo8); rows[k][r] = (lane < ch.n_wg) ? v : 0.0; }
+                for (int w0 = 64; w0 < ch.n_wg; w0 += 64) {
 #pragma unroll
-                for (int r = 0; r < P; ++r) if (w0 + lane < ch.n_wg) rows[k][r] += part[(size_t)(PK_TP + r) * ch.n_wg + w0 + lane];
+                    for (int r = 0; r < P; ++r) if (w0 + lane < ch.n_wg) rows[k][r] += part[(size_t)r * ch.n_wg + w0 + lane];
+                }
             }
         }
-        const int cc = min(c0 + wave * 4 + lj, nch - 1);               // this lane's own (chain 4 wave + lj, parameter li)
-        const LeafPlan* lp = ch.plan + (size_t)(parity ^ 1) * nch + cc;
-        const int lcur = lp->cur;
-        const double lhs = lp->hs, leps = lp->eps;
-        const bool lder = lp->active && !lp->skip && lp->leaf;
-        const int e = pb.ND + D + min(li, P - 1);
-        const double* vb = ch.vec + vec_off(pb, cc, 0);
-        const double qv = (vb + (size_t)(V_Q + lcur) * pb.dimp)[e], pv = (vb + (size_t)(V_P + lcur) * pb.dimp)[e];
-        const double parv = ch.par[(size_t)cc * PAR_COUNT + PAR_TH + min(li, P - 1)];
+        if (mine) {
+            const int cc = c0 + cg;
+            const LeafPlan* lp = ch.plan + (size_t)(parity ^ 1) * nch + cc;
+            lcur = lp->cur;
+            lhs = lp->hs; leps = lp->eps;
+            lder = lp->active && !lp->skip && lp->leaf;
+            const double* vb = ch.vec + vec_off(pb, cc, 0) + pb.ND + D + li;
+            qv0 = vb[(size_t)V_Q * pb.dimp]; qv1 = vb[(size_t)V_Q1 * pb.dimp];
+            pv0 = vb[(size_t)V_P * pb.dimp]; pv1 = vb[(size_t)V_P1 * pb.dimp];
+            parv = ch.par[(size_t)cc * PAR_COUNT + PAR_TH + li];
+        }
+    }
+    MC_STAMP(14);
+    // which of the 16 chain columns take part in this slot (bit c): every lane fetches its own chain's flag now, not at the stores
+    const bool valid = li < ngrp;
+    const unsigned long long actb = __ballot(valid && ch.plan[(size_t)(parity ^ 1) * nch + min(c0 + li, nch - 1)].active != 0);
+    // ---- (2) raw positions: column slice of block column bj (thread = (chain li, 4 of the 64 column pairs)), this wave's rows
+    //      of block row bi (column-type product only).  xop has Np rows per component: no clamp at the ragged end (those entries
+    //      are selected away below). ----
+    const int cw = xop_width(nch);
+    const double* xg = ch.xop + xop_off(pb, nch, parity, c0, 0, 0);                               // the group's mirror (wave-uniform)
+    const unsigned vcol = ((unsigned)(bj * TB + 2 * (t >> 4)) * (unsigned)cw + (unsigned)li) * 8u;   // + (32 k + hh) cw 8
+    const unsigned vrow = ((unsigned)(bi * TB + 32 * wave + lj) * (unsigned)cw + (unsigned)li) * 8u; // + (16 cidx + 4 q) cw 8
+    const unsigned cw8 = (unsigned)cw * 8u;
+    double xcol[4][2][D], xrow[2][4][D];
+    if (valid) {
+        if (colf) {
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) {
+                const double* xd = xg + (size_t)dd * pb.Np * cw;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) xcol[k][hh][dd] = ldb(xd, vcol + (unsigned)(32 * k + hh) * cw8);
+            }
+        } else {
+            const double* xd = xg + (size_t)d * pb.Np * cw;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) xcol[k][hh][0] = ldb(xd, vcol + (unsigned)(32 * k + hh) * cw8);
+        }
+        if (coltype) {
+            if (rowf) {
+#pragma unroll
+                for (int dd = 0; dd < D; ++dd) {
+                    const double* xd = xg + (size_t)dd * pb.Np * cw;
+#pragma unroll
+                    for (int cidx = 0; cidx < 2; ++cidx)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) xrow[cidx][q][dd] = ldb(xd, vrow + (unsigned)(16 * cidx + 4 * q) * cw8);
+                }
+            } else {
+                const double* xd = xg + (size_t)d * pb.Np * cw;
+#pragma unroll
+                for (int cidx = 0; cidx < 2; ++cidx)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xrow[cidx][q][0] = ldb(xd, vrow + (unsigned)(16 * cidx + 4 * q) * cw8);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    MC_STAMP(10);
+    // ---- (3) theta' ----
+    if (kind != TK_FH) {
         double tpp = 0.0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 4; ++k) {
+            if (k < kpw) {
 #pragma unroll
-            for (int r = 0; r < P; ++r) {
-                const double sres = wave_sum(rows[k][r]);
-                if (lj == k && li == r) tpp = sres;
+                for (int r = 0; r < P; ++r) {
+                    const double sres = wave_sum(rows[k][r]);
+                    if (lj == k && li == r) tpp = sres;
+                }
             }
+        }
+        MC_STAMP(11);
         double thp = parv;
-        if (lder && li < P) {
+        if (lder && mine) {
+            const double qv = lcur ? qv1 : qv0, pv = lcur ? pv1 : pv0;
             const double ex = m_exp(qv);
             const double sg = ex / (1.0 + ex);                       // == par[PAR_SGT] of that state (compute_par_entry)
             const double qnx = next_entry_pre(pv, qv, lhs, leps, theta_entry_grad(pb.beta_inv, tpp, sg));
             thp = m_log(1.0 + m_exp(qnx));                           // == par'[PAR_TH] (compute_par_entry)
         }
-        if (li < P) th_s[(wave * 4 + lj) * 8 + li] = thp;
+        if (mine) th_s[cg * 8 + li] = thp;
     }
     if (all_done) return;
+    MC_STAMP(1);
     __syncthreads();                 // th_s
+    MC_STAMP(2);
 
-    // ---- operand slices from the operand-order mirror of the state each chain's last plan leaves to be evaluated ----
+    // ---- (4) column slice -> LDS, [column pair][chain]; row slice W[32 wave + 16 cidx + 4 q + lj][chain li] -> registers ----
     const double mud = MAGI_SEL_D(pb.mu, d);
-    auto operand = [&](const double* xb /* chain's buffer base + chain column */, int i, bool wantf, const double (&thv)[P]) -> double {
-        const size_t comp = (size_t)pb.Np * 16;
-        if (!wantf) return xb[(size_t)d * comp + (size_t)i * 16] - mud;
-        double x[D];
+    double thv[P];
 #pragma unroll
-        for (int dd = 0; dd < D; ++dd) x[dd] = xb[(size_t)dd * comp + (size_t)i * 16];
-        return DR::f1(d, x, thv);
-    };
-    {   // column slice of block column bj -> LDS, [column pair][chain]: thread = (chain t & 15, 4 of the 64 column pairs)
-        const int c = t & 15, cc = min(c0 + c, nch - 1);
-        const LeafPlan* lp = ch.plan + (size_t)(parity ^ 1) * nch + cc;
-        const int buf = (lp->skip || !lp->leaf) ? lp->cur : (lp->cur ^ 1);
-        const double* xb = ch.xop + xop_off(pb, nch, buf, cc, 0, 0);
-        const bool valid = c0 + c < nch, wantf = kind == TK_FK;
-        double thv[P];
-#pragma unroll
-        for (int k = 0; k < P; ++k) thv[k] = (kind != TK_FH) ? th_s[c * 8 + k] : 0.0;
+    for (int k = 0; k < P; ++k) thv[k] = (kind != TK_FH) ? th_s[li * 8 + k] : 0.0;
+    {
         double2 vv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int cp = (t >> 4) + 16 * k, i0 = bj * TB + 2 * cp;
-            vv[k].x = (valid && i0 < pb.N) ? operand(xb, min(i0, pb.N - 1), wantf, thv) : 0.0;
-            vv[k].y = (valid && i0 + 1 < pb.N) ? operand(xb, min(i0 + 1, pb.N - 1), wantf, thv) : 0.0;
-            if (k & 1) __builtin_amdgcn_sched_barrier(0);          // (two column pairs' loads in flight at a time: more would not fit next to the tile ring)
+            const int i0 = bj * TB + 2 * ((t >> 4) + 16 * k);
+            double v0, v1;
+            if (colf) { v0 = DR::f1(d, xcol[k][0], thv); v1 = DR::f1(d, xcol[k][1], thv); }
+            else { v0 = xcol[k][0][0] - mud; v1 = xcol[k][1][0] - mud; }
+            vv[k].x = (valid && i0 < pb.N) ? v0 : 0.0;
+            vv[k].y = (valid && i0 + 1 < pb.N) ? v1 : 0.0;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) reinterpret_cast<double2*>(smem + MC_SM_V)[((t >> 4) + 16 * k) * MC + c] = vv[k];
+        for (int k = 0; k < 4; ++k) reinterpret_cast<double2*>(smem + MC_SM_V)[((t >> 4) + 16 * k) * MC + li] = vv[k];
     }
-    double wf[2][4];                                                   // W[32 wave + 16 cidx + 4 q + lj][chain li]: this wave's rows of block row bi
-    {
-        const int cc = min(c0 + li, nch - 1);
-        const LeafPlan* lp = ch.plan + (size_t)(parity ^ 1) * nch + cc;
-        const int buf = (lp->skip || !lp->leaf) ? lp->cur : (lp->cur ^ 1);
-        const double* xb = ch.xop + xop_off(pb, nch, buf, cc, 0, 0);
-        const bool valid = c0 + li < nch, wantf = kind != TK_FH;
-        double thv[P];
+    // ---- the tile ring: behind every operand load (the raw column slice has left its registers to it; one or two steps of it
+    //      in front of the operand loads were measured: 23.2 / 26.2 us against 22.7 -- they delay every workgroup's operands) ----
+    __builtin_amdgcn_sched_barrier(0);
+    MC_STAMP(12);
 #pragma unroll
-        for (int k = 0; k < P; ++k) thv[k] = (kind != TK_FH) ? th_s[li * 8 + k] : 0.0;
+    for (int s = 0; s < MC_RING - 1; ++s)
 #pragma unroll
-        for (int cidx = 0; cidx < 2; ++cidx)
+        for (int q = 0; q < 4; ++q) tl[s][q] = ld(s, q);
+    __builtin_amdgcn_sched_barrier(0);
+    double wf[2][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = bi * TB + 32 * wave + 16 * cidx + 4 * q + lj;
-                wf[cidx][q] = (valid && i < pb.N) ? operand(xb, min(i, pb.N - 1), wantf, thv) : 0.0;
-                if (q == 3) __builtin_amdgcn_sched_barrier(0);
-            }
-    }
+    for (int cidx = 0; cidx < 2; ++cidx)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = bi * TB + 32 * wave + 16 * cidx + 4 * q + lj;
+            double w0 = 0.0;
+            if (valid && coltype) w0 = rowf ? DR::f1(d, xrow[cidx][q], thv) : xrow[cidx][q][0] - mud;
+            wf[cidx][q] = (i < pb.N) ? w0 : 0.0;
+        }
+    MC_STAMP(3);
     __syncthreads();                 // operand image complete
+    MC_STAMP(4);
 
-    const bool coltype = (kind == TK_FE) || (bi != bj);      // (diagonal blocks of FH / FK are stored full: complete by rows)
     mc_d4 accc[2], accr[2];
     accr[0] = mc_d4{0.0, 0.0, 0.0, 0.0}; accr[1] = mc_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -504,6 +584,7 @@ void k_stream_mc(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
             __syncthreads();
         }
         __builtin_amdgcn_sched_barrier(0);      // (keeps the next steps' fragment reads out of this one: they would not fit the register file)
+        if (s & 1) MC_STAMP(5 + (s >> 1));
     }
 
     // ---- partials.  Accumulator layout: register r of lane (li, lj) = chain lj + 4 r, free index li. ----
@@ -514,17 +595,17 @@ void k_stream_mc(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int c = lj + 4 * r;
-        const bool act = (c0 + c < nch) && ch.plan[(size_t)(parity ^ 1) * nch + min(c0 + c, nch - 1)].active != 0;
+        const bool act = ((actb >> c) & 1ull) != 0;
 #pragma unroll
         for (int cidx = 0; cidx < 2; ++cidx)
             if (act)
                 ch.tpart[(size_t)(c0 + c) * cstride + ((size_t)(rvec * D + d) * pb.nb + bj) * pb.Np + bi * TB + 32 * wave + 16 * cidx + li] = accr[cidx][r];
     }
-    if (!coltype) return;
+    if (!coltype) { MC_STAMP(9); return; }
     // column-type: complete in LDS after the last phase's barrier; thread = (chain t >> 4, eight columns)
     {
         const int c = t >> 4, col = 8 * (t & 15);
-        const bool act = (c0 + c < nch) && ch.plan[(size_t)(parity ^ 1) * nch + min(c0 + c, nch - 1)].active != 0;
+        const bool act = ((actb >> c) & 1ull) != 0;
         if (act) {
             double2* dst = reinterpret_cast<double2*>(&ch.tpart[(size_t)(c0 + c) * cstride + ((size_t)(cvec * D + d) * pb.nb + bi) * pb.Np + bj * TB + col]);
             const double2* src = reinterpret_cast<const double2*>(&colsum[c * TB + col]);
@@ -532,6 +613,7 @@ void k_stream_mc(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
             for (int k = 0; k < 4; ++k) dst[k] = src[k];
         }
     }
+    MC_STAMP(9);
 }
 
 // ---- point kernel: the elementwise half of slot `parity` (leap_point.h), N / 16 workgroups per chain -------------------------
@@ -547,7 +629,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains c
     kernarg_prefetch<sizeof(DevProblem) + sizeof(DevChains) + sizeof(int)>();
     const int gate = all_done | (lp.active ^ 1) | lp.skip;
     if (gate != 0) return;
-    point_block<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, res, redk, s_mu);
+    point_block<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, res, redk, s_mu, parity ^ 1);
 }
 
 // load-only twin of k_stream's tile stream (bench.py's ceiling leg): every workgroup reads its 128 KB block with the same

@@ -54,7 +54,7 @@ struct GridPoint {     // component d of grid index i of one chain (one lane)
     // `mud` = mu[d], read by the caller from an LDS copy: selecting pb.mu[d] with a per-lane d makes the compiler spill the
     // kernel-argument array to scratch and index it there -- a global-memory round trip in the middle of the finishing lane
     static __device__ __forceinline__ void finish(const DevProblem& pb, const DevChains& ch, const LeafPlan& lp, int cc, int i, int d, const Ops& o,
-                                                  const double* res /* [D][4] */, double mud, double* pk /* [PART_K] */) {
+                                                  const double* res /* [D][4] */, double mud, double* pk /* [PART_K] */, int xop_buf) {
 #pragma unroll
         for (int k = 0; k < PART_K; ++k) pk[k] = 0.0;
         const int N = pb.N, dimp = pb.dimp;
@@ -102,7 +102,7 @@ struct GridPoint {     // component d of grid index i of one chain (one lane)
             *(vb + (size_t)(V_P + (lp.cur ^ 1)) * dimp + e) = pnext;
             const double xn = xd + lp.eps * pnext;
             *(vb + (size_t)(V_Q + (lp.cur ^ 1)) * dimp + e) = xn;
-            if (ch.n_chains >= 3) ch.xop[xop_off(pb, ch.n_chains, lp.cur ^ 1, cc, d, i)] = xn;      // (three or more chains: the matrix-core stream reads this mirror)
+            if (ch.n_chains >= 3) ch.xop[xop_off(pb, ch.n_chains, xop_buf, cc, d, i)] = xn;      // (three or more chains: the matrix-core stream of the NEXT slot reads this mirror)
         }
     }
 };
@@ -110,7 +110,8 @@ struct GridPoint {     // component d of grid index i of one chain (one lane)
 // All PT_THREADS threads of the block must call it.  res: PT_POINTS*PT_DSLOT*4 doubles, redk: 64*PART_K doubles of LDS.
 // Writes part[cc][k][blk].  `lp`: the chain's plan for this slot (active, not skip).
 template <int DRIFT>
-__device__ __forceinline__ void point_block(const DevProblem& pb, const DevChains& ch, const LeafPlan& lp, int cc, int blk, double* res, double* redk, double* s_mu /* MAGI_MAX_D */) {
+__device__ __forceinline__ void point_block(const DevProblem& pb, const DevChains& ch, const LeafPlan& lp, int cc, int blk, double* res, double* redk, double* s_mu /* MAGI_MAX_D */,
+                                            int xop_buf /* slot parity ^ 1 */) {
     using GP = GridPoint<DRIFT>;
     constexpr int D = GP::D, TB = MAGI_TB;
     const unsigned t = threadIdx.x;
@@ -154,7 +155,7 @@ __device__ __forceinline__ void point_block(const DevProblem& pb, const DevChain
     if (t < 64) {
         double* pk = redk + (size_t)t * PART_K;
         if (fvalid) {
-            GP::finish(pb, ch, lp, cc, fi, fd, ops, res + fpt * PT_DSLOT * 4, s_mu[fd], pk);
+            GP::finish(pb, ch, lp, cc, fi, fd, ops, res + fpt * PT_DSLOT * 4, s_mu[fd], pk, xop_buf);
         } else {
 #pragma unroll
             for (int k = 0; k < PART_K; ++k) pk[k] = 0.0;

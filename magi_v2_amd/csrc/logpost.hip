@@ -220,11 +220,12 @@ __global__ void k_prepare(DevProblem pb, DevChains ch) {
     const int c = blockIdx.x, j = threadIdx.x;
     if (j < pb.D + pb.P)
         compute_par_entry(pb, j, ch.vec[vec_off(pb, c, V_Q) + pb.ND + j], ch.par + (size_t)c * PAR_COUNT);
-    // operand-order mirror of position buffer 0 (matrix-core streaming kernel)
+    // operand-order mirror of the positions (matrix-core streaming kernel; both slot parities)
     const double* q = ch.vec + vec_off(pb, c, V_Q);
     for (int e = j; e < pb.ND; e += blockDim.x) {
         const int d = e / pb.N, i = e - d * pb.N;
         ch.xop[xop_off(pb, ch.n_chains, 0, c, d, i)] = q[e];
+        ch.xop[xop_off(pb, ch.n_chains, 1, c, d, i)] = q[e];
     }
 }
 

@@ -176,8 +176,10 @@ struct DevChains {
     double* part;         // [n_chains][PART_K][n_wg] partial sums of the point kernel
     int n_wg;             // workgroups along the grid axis of k_point
     double* tpart;        // [n_chains][4 (hx, ex, etf, kf)][D][nb][Np] block partials of the streaming kernel
-    double* xop;          // [2 position buffers][ceil(n_chains / 16)][D][Np][16 chains]: mirror of the X part of V_Q / V_Q1 in the operand order of
-                          // the matrix-core streaming kernel (a block's slice of 16 chains is contiguous); kept by whoever writes those buffers
+    double* xop;          // [2 slot parities][ceil(n_chains / 16)][D][Np][16 chains]: the positions the stream of slot s evaluates, in the operand
+                          // order of the matrix-core streaming kernel (a block's slice of 16 chains is contiguous), at xop[s & 1]: written by whoever
+                          // sets that state up during slot s - 1 (the point phase's speculative next leaf, the decisions' new subtree start,
+                          // k_prepare) -- the stream needs no plan to find it
     double* par;          // [n_chains][PAR_COUNT] transformed parameters of the state in V_Q
     GlobalCtl* gctl;
     int n_chains;
@@ -193,10 +195,13 @@ struct DevChains {
     int* d_flags;         // bit0 has_divergence, bit1 reach_max_depth, bit2 is_accepted
 };
 
-// element (buffer b, chain, component d, grid index i) of the operand-order mirror
+// element (slot parity b, chain, component d, grid index i) of the operand-order mirror.  A grid point's chains are contiguous:
+// 16 per point (one 128-B line), or 8 (64 B) when there are at most 8 chains -- every stream workgroup reads its operand slices of
+// all chains from here, and with half-empty lines that traffic (L2 hits, in one burst at the kernel's start) is twice what it must be.
+__host__ __device__ inline int xop_width(int n_chains) { return n_chains <= 8 ? 8 : 16; }
 __host__ __device__ inline size_t xop_off(const DevProblem& pb, int n_chains, int b, int chain, int d, int i) {
     const size_t groups = (size_t)((n_chains + 15) >> 4);
-    return ((((size_t)b * groups + (size_t)(chain >> 4)) * pb.D + d) * (size_t)pb.Np + i) * 16 + (chain & 15);
+    return ((((size_t)b * groups + (size_t)(chain >> 4)) * pb.D + d) * (size_t)pb.Np + i) * xop_width(n_chains) + (chain & 15);
 }
 
 __host__ __device__ inline size_t vec_off(const DevProblem& pb, int chain, int slot) {
