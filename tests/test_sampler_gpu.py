@@ -140,3 +140,51 @@ def test_fixed_length_hmc_matches_oracle(L):
     np.testing.assert_allclose(tp[0], otp, rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(Xs[0], oX, rtol=0, atol=1e-8 * np.abs(oX).max())
     eng.close()
+
+
+def test_pause_resume_equals_single_run_on_the_matrix_core_kernel():
+    """Five chains (the matrix-core streaming kernel, whose operand mirror is indexed by slot parity): stopping and resuming at
+    transition boundaries -- every resume starts a new graph at slot parity 0 -- gives the samples of an uninterrupted run."""
+    g = load_g4("sirw_N41")
+    pr = problem_from_g4(g, None)
+    outs = []
+    for chunks in ([9], [2, 1, 4, 2]):
+        eng = engine_for(pr, None)
+        X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], np.ones(pr.P), pr.LB)
+        cfg = eng.default_cfg(num_results=4, num_burnin_steps=5)
+        rep = lambda v: np.repeat(np.asarray(v)[None], 5, axis=0)
+        eng.sampler_init(cfg, rep(X0), rep(s0), rep(t0), seed=11, chain_ids=[0, 1, 2, 3, 4])
+        for c in chunks:
+            eng.sampler_run(c)
+        assert list(eng.sampler_steps_done()) == [9] * 5
+        outs.append(eng.sampler_samples())
+        eng.close()
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
+    assert not np.allclose(outs[0][2][0], outs[0][2][1])
+
+
+def test_fixed_length_hmc_batched_matches_oracle():
+    """Fixed-L HMC with four chains in one batch (matrix-core streaming kernel) against the oracle, chain by chain."""
+    g = load_g4("seir4_N81")
+    pr = problem_from_g4(g, None)
+    eng = engine_for(pr, None)
+    theta0 = np.ones(pr.P)
+    X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], theta0, pr.LB)
+    burnin, results, L, ids = 8, 4, 5, [3, 0, 7, 1]
+    cfg = eng.default_cfg(num_results=results, num_burnin_steps=burnin, mode=1, hmc_leapfrogs=L)
+    rep = lambda v: np.repeat(np.asarray(v)[None], len(ids), axis=0)
+    eng.sampler_init(cfg, rep(X0), rep(s0), rep(t0), seed=77, chain_ids=ids)
+    lf, _ = eng.sampler_run(burnin + results)
+    assert lf == len(ids) * L * (burnin + results)
+    Xs, sp, tp = eng.sampler_samples()
+    d = eng.sampler_diag()
+    eng.close()
+    for i, cid in enumerate(ids):
+        trace = []
+        oX, osp, otp, info, _ = orc.sample_chain(pr, g["Xhat_init"], g["sigma_sqs_init"], theta0, results, burnin, seed=77, chain=cid,
+                                                 trace=trace, hmc_leapfrogs=L)
+        np.testing.assert_array_equal(d.is_accepted[i], [int(r.is_accepted) for _, r, _ in trace])
+        np.testing.assert_allclose(d.step_size[i], [s for _, _, s in trace], rtol=1e-8)
+        np.testing.assert_allclose(tp[i], otp, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(Xs[i], oX, rtol=0, atol=1e-8 * np.abs(oX).max())
