@@ -109,12 +109,21 @@ struct GridPoint {     // component d of grid index i of one chain (one lane)
 
 // All PT_THREADS threads of the block must call it.  res: PT_POINTS*PT_DSLOT*4 doubles, redk: 64*PART_K doubles of LDS.
 // Writes part[cc][k][blk].  `lp`: the chain's plan for this slot (active, not skip).
+#ifdef MAGI_PT_STAMPS      // dev: 100 MHz stamps of workgroup MAGI_PT_STAMPS of k_point, kept in scalar registers, written at the end to par[40 ..] of chain 0
+#define PT_STAMP(i) do { pt_st[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PT_STAMP(i) do { } while (0)
+#endif
 template <int DRIFT>
 __device__ __forceinline__ void point_block(const DevProblem& pb, const DevChains& ch, const LeafPlan& lp, int cc, int blk, double* res, double* redk, double* s_mu /* MAGI_MAX_D */,
                                             int xop_buf /* slot parity ^ 1 */) {
     using GP = GridPoint<DRIFT>;
     constexpr int D = GP::D, TB = MAGI_TB;
     const unsigned t = threadIdx.x;
+#ifdef MAGI_PT_STAMPS
+    unsigned long long pt_st[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+#endif
+    PT_STAMP(0);
     // finishing lanes: t < 64 = (component, point)
     const int fpt = t & (PT_POINTS - 1), fd = (t / PT_POINTS) & (PT_DSLOT - 1);
     const int fi = blk * PT_POINTS + fpt;
@@ -147,11 +156,13 @@ __device__ __forceinline__ void point_block(const DevProblem& pb, const DevChain
         }
         res[(pt * PT_DSLOT + d) * 4 + v] = sum;
     }
+    PT_STAMP(1);
     if (t == PT_THREADS - 1) {
 #pragma unroll
         for (int k = 0; k < MAGI_MAX_D; ++k) s_mu[k] = pb.mu[k];       // (static indices: one thread copies the kernel-argument array)
     }
     __syncthreads();
+    PT_STAMP(2);
     if (t < 64) {
         double* pk = redk + (size_t)t * PART_K;
         if (fvalid) {
@@ -161,11 +172,23 @@ __device__ __forceinline__ void point_block(const DevProblem& pb, const DevChain
             for (int k = 0; k < PART_K; ++k) pk[k] = 0.0;
         }
     }
+    PT_STAMP(3);
     __syncthreads();
-    if (t < PART_K) {
+    PT_STAMP(4);
+    // PART_K sums over the 64 finishing lanes: four threads per sum, 16 lanes each in order, then (s0 + s1) + (s2 + s3) by two quad
+    // exchanges (one thread per sum, 64 dependent additions: 0.64 us of the kernel's 2.5 us behind the plan)
+    if (t < 4 * PART_K) {
+        const int k = t >> 2, q = t & 3;
         double s = 0.0;
-#pragma unroll 8
-        for (int u = 0; u < 64; ++u) s += redk[u * PART_K + t];
-        *(&ch.part[((size_t)cc * PART_K + t) * ch.n_wg + blk]) = s;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += redk[(16 * q + u) * PART_K + k];
+        s += dpp_f64<0xB1>(s);    // quad_perm [1,0,3,2]
+        s += dpp_f64<0x4E>(s);    // quad_perm [2,3,0,1]
+        if (q == 0) *(&ch.part[((size_t)cc * PART_K + k) * ch.n_wg + blk]) = s;
     }
+    PT_STAMP(5);
+#ifdef MAGI_PT_STAMPS
+    if (blk == (MAGI_PT_STAMPS) && cc == 0 && t == 0)
+        for (int _i = 0; _i < 8; ++_i) reinterpret_cast<unsigned long long*>(ch.par + 40)[_i] = pt_st[_i];
+#endif
 }
