@@ -226,11 +226,22 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
                 const double* cp = v.ckp + (size_t)__popc((unsigned)left) * sv;
                 const double* cr = v.ckrho + (size_t)__popc((unsigned)left) * sv;
                 double dots[2] = {0.0, 0.0};
-#pragma unroll 4
-                for (int e = tid; e < dim; e += blockDim.x) {     // (no stores: unrolling puts four elements' loads in flight together)
-                    const double df = v.rhosub[e] - cr[e];
-                    dots[0] = fma(df, cp[e], dots[0]);
-                    dots[1] = fma(df, pleaf[e], dots[1]);
+                constexpr int DBU = 8;           // (no stores: eight elements' loads of the four vectors in flight together -- two round trips at dim = 4 103)
+                for (int e0 = tid; e0 < dim; e0 += DBU * (int)blockDim.x) {
+                    double rs[DBU], crv[DBU], cpv[DBU], plv[DBU];
+#pragma unroll
+                    for (int u = 0; u < DBU; ++u) {
+                        const int e = min(e0 + u * (int)blockDim.x, dim - 1);
+                        rs[u] = v.rhosub[e]; crv[u] = cr[e]; cpv[u] = cp[e]; plv[u] = pleaf[e];
+                    }
+#pragma unroll
+                    for (int u = 0; u < DBU; ++u) {
+                        if (e0 + u * (int)blockDim.x < dim) {
+                            const double df = rs[u] - crv[u];
+                            dots[0] = fma(df, cpv[u], dots[0]);
+                            dots[1] = fma(df, plv[u], dots[1]);
+                        }
+                    }
                 }
                 block_sum<2>(dots, sh);
                 no_u = no_u && (dots[0] > 0.0) && (dots[1] > 0.0);
