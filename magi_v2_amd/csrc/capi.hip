@@ -550,7 +550,8 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
     bool done = false;
     // every slot advances every unfinished chain by a leaf or a set-up step, so a transition takes at most 2^max_depth - 1 leaves
     // + one set-up slot per doubling + start / end: a pump that outlives that budget means a corrupted control block
-    const long long per_transition = (h->cfg.mode == MAGI_MODE_HMC ? (long long)h->cfg.hmc_L : (1ll << (h->cfg.max_depth + 1))) + h->cfg.max_depth + 4;
+    // (+ one more set-up slot per doubling and two per transition end when a batch of NUTS chains spreads those passes: decide.h)
+    const long long per_transition = (h->cfg.mode == MAGI_MODE_HMC ? (long long)h->cfg.hmc_L : (1ll << (h->cfg.max_depth + 1))) + 2 * h->cfg.max_depth + 8;
     const long long max_graphs = ((long long)(g.stop_k - kmin) * per_transition + 8) / kGraphSlots + 4;
     while (!done) {
         if (issued >= max_graphs && issued == retired) {

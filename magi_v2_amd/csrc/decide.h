@@ -173,7 +173,19 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
         }
         return;
     }
-    if (c.phase == PH_IDLE) {
+    // Batches of NUTS chains (three or more per GPU): a subtree end (merge pass, then the set-up pass of the next doubling) or a
+    // transition end (merge, sample, momentum draw, set-up) keeps ONE workgroup busy for 25-100 us while every other chain's slot
+    // waits for the kernel to end -- with eight chains a quarter of the slots carried such a tail (k_stream_mc 26.2 us in the sampler
+    // against 22.7 us by itself).  There the passes go into consecutive slots, each short enough to hide under the stream: the chain
+    // publishes an idle plan in between (its point phase and the stream's output for it are off), at the price of one or two more
+    // set-up slots per subtree for that chain.  Fixed-L HMC chains end their transitions in step: nothing to gain, left alone.
+    const bool spread = !hmc && ch.n_chains >= 3;
+    const int phase_in = c.phase;
+    if (c.phase == PH_PEND_DOUBLE) {
+        do_doubling = true;
+    } else if (c.phase == PH_PEND_SAMPLE) {
+        do_sample = true;
+    } else if (c.phase == PH_IDLE) {
         if (c.k < stop_k) {
             do_sample = true;                        // resumed by a later magi_sampler_run
         } else {
@@ -335,6 +347,11 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
             const bool continue_tree = !hmc && (c.cont != 0) && no_u_traj;
             if (hmc) { c.e_sum = shs[19]; }          // acceptance statistic of HMC: min(1, exp(energy difference))
             if (c.depth < cfg.max_depth && continue_tree) {
+                if (spread) {
+                    c.phase = PH_PEND_DOUBLE;
+                    if (tid == 0) { LeafPlan off{}; *plan_out = off; ch.ctl[chain] = c; }
+                    return;
+                }
                 do_doubling = true;
             } else {
                 // ---- transition finished ------------------------------------------------------------------
@@ -374,6 +391,11 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
                         const int done = atomicAdd(&ch.gctl->done_chains, 1) + 1;
                         if (done >= ch.gctl->n_chains) ch.gctl->all_done = 1;
                     }
+                    return;
+                }
+                if (spread) {
+                    c.phase = PH_PEND_SAMPLE;
+                    if (tid == 0) { LeafPlan off{}; *plan_out = off; ch.ctl[chain] = c; }
                     return;
                 }
                 do_sample = true;
@@ -428,6 +450,11 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
         c.is_accepted = 0;
         c.depth = 0;
         c.leaf_ctr = 0;
+        if (spread && phase_in == PH_PEND_SAMPLE) {
+            c.phase = PH_PEND_DOUBLE;
+            if (tid == 0) { LeafPlan off{}; *plan_out = off; ch.ctl[chain] = c; }
+            return;
+        }
         do_doubling = true;
     }
 

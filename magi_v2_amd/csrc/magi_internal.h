@@ -92,7 +92,8 @@ enum VecSlot {
     V_COUNT = V_CKRHO0 + MAGI_MAX_DEPTH
 };
 
-enum ChainPhase { PH_INIT = 0, PH_LEAF = 1, PH_IDLE = 2 };
+enum ChainPhase { PH_INIT = 0, PH_LEAF = 1, PH_IDLE = 2,
+                  PH_PEND_DOUBLE = 3, PH_PEND_SAMPLE = 4 };   // a subtree / transition end spread over several slots (decide.h: batches of chains)
 
 // Per-chain scalar state of the device-resident sampler ---------------------------------------
 struct ChainCtl {
