@@ -20,13 +20,17 @@ MAGI_GRAPH_SLOTS=2 timeout -k 10 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_build8k -- python3 tools/exp_build_once.py 8192 3 > $O/kt_build8k.log 2>&1 || exit 1
 MAGI_BUILD_PROFILE=1 timeout -k 10 200 python3 tools/exp_build_profile.py 8192 > $O/build_profile_n8192.json 2> $O/build_profile.err || exit 1
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $O/pmc_gemm -- python3 tools/exp_build_once.py 8192 > $O/pmc_gemm.log 2>&1 || exit 1
-# 5. micro
+# 5. micro; the matrix-core streaming kernel by chain count; the 8-chain sampler's kernel durations on the graph path
 timeout -k 5 60 tools/micro/readshape > $O/micro_readshape.txt 2>&1
+timeout -k 5 60 tools/micro/dispatch > $O/micro_dispatch.txt 2>&1
+timeout -k 10 200 python3 tools/exp_mc.py 1024 3 8 16 > $O/mc_kernel.txt 2>&1
+MAGI_GRAPH_SLOTS=2 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/kt8_graph2 -- python3 bench.py --steps 4 --warmup 1 --burnin 30 --chains-per-gpu 8 --no-cpu-baseline > $O/kt8_graph2.log 2>&1
 # 6. summaries on the box; the raw per-launch csv files (tens of MB) stay behind: gpurun returns at most 64 MiB
 python3 tools/pmc_summary.py $O/pmc_traffic_summary.csv $O/pmc_fetch $O/pmc_write > /dev/null
 python3 tools/pmc_summary.py $O/pmc_l2_summary.csv $O/pmc_l2 > /dev/null
 python3 tools/pmc_summary.py $O/pmc_gemm_summary.csv $O/pmc_gemm > /dev/null
 python3 tools/trace_summary.py $(ls $O/kt_graph2/*/*kernel_trace.csv | head -1) > $O/kt_graph2_summary.txt
+python3 tools/trace_summary.py $(ls $O/kt8_graph2/*/*kernel_trace.csv | head -1) > $O/kt8_graph2_summary.txt
 find $O -name "*kernel_trace.csv" -delete
 find $O -name "*counter_collection.csv" -delete
 du -sh $O
