@@ -60,6 +60,19 @@ constexpr int ST_RW = MAGI_TB / ST_WAVES;      // rows of the block per wave
 //   column-type products (A^T v_row)[c] -> per-lane accumulators, combined over the waves in LDS
 // where v is xc = X_d - mu_d or f_d = drift_d(X, theta) as the operator requires (evaluated on the fly from the
 // state vector).  The partials go to tpart[chain][vec][d][other block][i]; k_point adds them in fixed order.
+#ifdef MAGI_ST_STAMPS      // dev: 100 MHz time stamps of ONE stream workgroup (task MAGI_ST_STAMPS, wave MAGI_ST_STAMP_WAVE) into par[40 ..] of chain 0
+#ifndef MAGI_ST_STAMP_WAVE //      (tools/exp_st_stamps.py); kept in scalar registers and written once at the end -- a store per stamp spills the kernel (12 -> 27 us)
+#define MAGI_ST_STAMP_WAVE 1
+#endif
+#define ST_STAMP_DECL unsigned long long st_stamps[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}
+#define ST_STAMP(i) do { st_stamps[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ST_STAMP_FLUSH() do { if ((int)blockIdx.x - n_dec == (MAGI_ST_STAMPS) && blockIdx.y == 0 && threadIdx.x == 64 * (MAGI_ST_STAMP_WAVE)) \
+    for (int _i = 0; _i < 8; ++_i) reinterpret_cast<unsigned long long*>(ch.par + 40)[_i] = st_stamps[_i]; } while (0)
+#else
+#define ST_STAMP_DECL do { } while (0)
+#define ST_STAMP(i) do { } while (0)
+#define ST_STAMP_FLUSH() do { } while (0)
+#endif
 template <int NC, int DRIFT>
 __global__ __launch_bounds__(64 * ST_WAVES) __attribute__((amdgpu_waves_per_eu(NC <= 2 ? 3 : 2)))
 void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
@@ -87,6 +100,8 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int tix = (int)blockIdx.x - n_dec;
+    ST_STAMP_DECL;
+    ST_STAMP(0);
     // (the descriptor table is read-only for the lifetime of the matrices: fetched through the constant address space it is a
     //  scalar load on its own counter, so waiting for it does not wait for the tile loads issued below and vice versa)
     typedef const int __attribute__((address_space(4))) * const_int_ptr;
@@ -153,6 +168,7 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
             thp = ch.par[(size_t)cc * PAR_COUNT + PAR_TH + lane];
         }
         if (lane < P) th_s[c][lane] = thp;
+        ST_STAMP(1);
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -181,8 +197,10 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     }
     __builtin_amdgcn_sched_barrier(0);
     double thv[NC][P];
+    ST_STAMP(2);
     if (kind != TK_FH) {
         __syncthreads();             // th_s
+        ST_STAMP(3);
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -204,6 +222,7 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
         if (t < 2 * TB) (isrow ? vrow : vcol)[c][loc] = val;
     }
     __syncthreads();
+    ST_STAMP(4);
 
     constexpr int NACC = ALT ? NCK : 1;            // column accumulators per physical chunk (direction-independent sums)
     double2 vc[NC], cacc[NC][NACC];
@@ -256,7 +275,9 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
         }
         *reinterpret_cast<double2*>(&colacc[wave][c][2 * lane]) = tot;
     }
+    ST_STAMP(5);
     __syncthreads();
+    ST_STAMP(6);
 
     // partials: threads [0, TB) the row-type output (block row bi, slot bj), threads [TB, 2 TB) the
     // column-type output (block row bj, slot bi; the diagonal blocks of FH / FK are complete by rows)
@@ -277,6 +298,8 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
             tp[((size_t)(cvec * D + d) * pb.nb + bi) * pb.Np + bj * TB + loc] = sum;
         }
     }
+    ST_STAMP(7);
+    ST_STAMP_FLUSH();
 #ifdef MAGI_TAIL_STAMPS
     __syncthreads();
     if (threadIdx.x == 0)
