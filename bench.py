@@ -3,16 +3,22 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): SEIR-4 (S, E, I, R explicit), N = 1024
-grid points (dt = 0.025, observations at even indices, noise 0.05 * range, PCG64(0)), dense
-matrices, hyper-parameters at the reference's starting values, theta_init = (1, 1, 1), NUTS (max
-tree depth 10) with dual averaging and the logarithmic annealing schedule -- i.e. the reference's
-predict() sampler (magi_v2.py:357-396) -- one chain per GPU.  A "step" is one NUTS transition of
-every chain on the rank.  Setup (data, GPU matrix build, 400 burn-in transitions that adapt the step size) is
-untimed; the timed region is exactly K transitions with all inputs resident in HBM.
+Workload of the headline `value` (BASELINE.json configs[1]): SEIR-4 (S, E, I, R explicit),
+N = 1024 grid points (dt = 0.025, observations at even indices, noise 0.05 * range, PCG64(0)), dense matrices,
+hyper-parameters at the reference's starting values, theta_init = (1, 1, 1), NUTS (max tree depth 10) with dual
+averaging and the logarithmic annealing schedule -- i.e. the reference's predict() sampler (magi_v2.py:357-396) -- one
+chain per GPU (`--chains-per-gpu 8` = BASELINE config 3's per-GPU share).  A "step" is one NUTS transition of every
+chain on the rank.  Setup (data, GPU matrix build, 400 burn-in transitions that adapt the step size) is untimed; the
+timed region is exactly K transitions with all inputs resident in HBM.
 
-One rank per GPU (torchrun); chains are independent (no data-path collective); the post-burn-in
-samples of all ranks are gathered once to rank 0 over RCCL after the timed region.
+One rank per GPU (torchrun); chains are independent (no data-path collective); the post-burn-in samples of all ranks
+are gathered once to rank 0 over RCCL after the timed region.
+
+After the headline region a one-GPU run (N = 1) also measures, untimed-setup style, the single-GPU figures of the other
+BASELINE configs -- config 1 (SEIR-4, N = 161, b = 80, one chain, 200 + 200 NUTS steps, next to the torch-CPU leg),
+config 3's per-GPU share (8 chains, N = 1024), one dataset of config 4's alpha sweep (8 chains, N = 161, b = 80) and
+config 5 (N = 8192 x 4: one pooled build with per-class device times, and the streaming kernel on 4.4 GB of operator
+blocks) -- and reports them as FLAT scalars inside `roofline` (`cfg1_*`, `mc8_*`, `cfg4_*`, `n8192_*`).
 """
 import argparse
 import json
@@ -27,31 +33,75 @@ import numpy as np
 import torch            # first: owns the HIP runtime the extension then shares
 import torch.distributed as dist
 
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md
+FP64_MFMA_PEAK_TFLOPS = 78.6    # AMD spec (the guide has no fp64 row)
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=int, default=1024, help="N grid points")
     ap.add_argument("--chains-per-gpu", type=int, default=1,
-                    help="chains sampled on every GPU.  1 = BASELINE config 2 (the N=1 headline); 8 = config 3 "
-                         "(64 independent chains over 8 GPUs): python -m torch.distributed.run ... bench.py --gpus 8 --chains-per-gpu 8")
+                    help="chains sampled on every GPU.  1 = BASELINE config 2 (the N=1 headline; N > 1: its weak scaling, one chain per "
+                         "GPU); 8 = config 3 (64 independent chains over 8 GPUs): python -m torch.distributed.run ... bench.py --gpus 8 "
+                         "--chains-per-gpu 8")
     ap.add_argument("--burnin", type=int, default=400,
                     help="untimed burn-in transitions before warmup (80 %% of them adapt the step size, magi_v2.py:365).  400: the dual-averaging "
                          "step size has flattened by then (1.3e-3 after 40 steps, 2.1e-3 after 100, 2.5e-3 after 200, 2.8e-3 after 400 on this "
-                         "workload), i.e. the timed transitions are those of an adapted sampler; with 40 (round 1) the trees of most chains are "
-                         "twice as long as in steady state and the spread between chains is 1.5x (DESIGN.md section 5)")
+                         "workload), i.e. the timed transitions are those of an adapted sampler (DESIGN.md section 5)")
     ap.add_argument("--band", type=int, default=-1, help="bandsize (-1 = dense)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2, help="oracle NUTS transitions for the CPU baseline")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the config 1 / 3 / 4 / 5 legs of a one-GPU run")
+    ap.add_argument("--cpu-steps", type=int, default=2, help="oracle NUTS transitions for the CPU baseline's numpy leg")
     ap.add_argument("--seed", type=int, default=20250103)
     ap.add_argument("--replicate-chains", action="store_true",
                     help="DIAGNOSTIC ONLY: every rank samples the chain ids of rank 0 (identical per-GPU work, bit-identical "
                          "chains).  The default gives every chain of the job its own Philox stream -- independent chains, as "
                          "BASELINE config 3 asks -- so the max-over-ranks time includes the NUTS tree-size spread between chains")
     ap.add_argument("--cpu-threads", type=str, default="1,8,32,all", help="thread counts of the torch-CPU baseline leg")
+    ap.add_argument("--profile-slots", type=int, default=512, help="leapfrog slots of the in-sampler kernel-duration leg")
     return ap.parse_args()
+
+
+def setup_problem(host, I, X_obs, P):
+    """Host-side constants of a problem (reference: magi_v2.py:85-100, 105, 114, 277, 299-300) at the reference's STARTING hyper-parameters."""
+    Xi = host.linear_interpolate(X_obs)
+    hp = host.hparams_initial(Xi)
+    N_ds, beta, idx, y = host.observation_bookkeeping(X_obs, X_obs)
+    Xhat = host.cubic_smoother(I, Xi)
+    LB = host.sigma_sqs_lower_bound(Xhat)
+    sig_pre0, th_pre0 = host.softplus_inverse_inits(hp["sigma_sqs"], np.ones(P), LB)
+    return dict(I=I, Xi=Xi, hp=hp, N_ds=N_ds.astype(np.float64), beta=float(beta), idx=idx, y=y, Xhat=Xhat, LB=LB, sig_pre0=sig_pre0,
+                th_pre0=th_pre0, mu=Xi.mean(axis=0))
+
+
+def timed_run(eng, cfg, pb, n_chains, chain_ids, seed, burnin, warmup, steps):
+    """init + untimed burn-in / warm-up + `steps` timed transitions on one engine; host wall time around the timed run."""
+    rep = lambda v: np.repeat(np.asarray(v)[None], n_chains, axis=0)
+    eng.sampler_init(cfg, rep(pb["Xhat"]), rep(pb["sig_pre0"]), rep(pb["th_pre0"]), seed=seed, chain_ids=chain_ids)
+    eng.sampler_run(burnin)
+    if warmup > 0:
+        eng.sampler_run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lf, dev_ms = eng.sampler_run(steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    slots, _ = eng.sampler_run_stats()
+    return el, lf, dev_ms, slots
+
+
+def cpu_gradient_rates(pb, mats, band, drift, P, state, threads, max_seconds):
+    """torch-CPU fp64 restatement of magi_v2.py:308-348 (oracle/torch_cpu.py): value+gradient evaluations per second per thread count."""
+    from oracle import magi_oracle as orc
+    from oracle import torch_cpu
+    C_inv, m, K_inv = mats
+    pr = orc.Problem(I=pb["I"], mu=pb["mu"], C_inv=orc.band_part(C_inv, band), m=orc.band_part(m, band), K_inv=orc.band_part(K_inv, band),
+                     N_ds=pb["N_ds"], obs_idx=pb["idx"], y=pb["y"], beta=pb["beta"], LB=pb["LB"], drift=drift, P=P)
+    Xc, spc, tpc = state
+    return pr, torch_cpu.time_gradients(pr, Xc, spc, tpc, threads, min_evals=200, max_seconds=max_seconds)
 
 
 def main():
@@ -76,6 +126,7 @@ def main():
 
     from magi_v2_amd import host
     from magi_v2_amd.engine import MagiEngine
+    from magi_v2_amd.shard import chain_ids_for_rank, gather_samples
 
     N, D, P = a.grid, 4, 3
     cpg = a.chains_per_gpu
@@ -83,31 +134,25 @@ def main():
 
     # ---- setup (untimed) -----------------------------------------------------------------------
     I, X_obs, truth, theta_true = host.synthetic_seir(N, seed=0)
-    Xi = host.linear_interpolate(X_obs)
-    hp = host.hparams_initial(Xi)
-    N_ds, beta, idx, y = host.observation_bookkeeping(X_obs, X_obs)
-    Xhat = host.cubic_smoother(I, Xi)
-    LB = host.sigma_sqs_lower_bound(Xhat)
-    sig_pre0, th_pre0 = host.softplus_inverse_inits(hp["sigma_sqs"], np.ones(P), LB)
-
+    pb = setup_problem(host, I, X_obs, P)
     eng = MagiEngine(dev_index)
     t0 = time.perf_counter()
     want_host = (rank == 0 and world == 1 and not a.no_cpu_baseline)
-    mats = eng.build_matrices(I, hp["phi1s"], hp["phi2s"], 2.01, bandsize=band, want_host=want_host)
+    mats = eng.build_matrices(I, pb["hp"]["phi1s"], pb["hp"]["phi2s"], 2.01, bandsize=band, want_host=want_host)
     build_ms = (time.perf_counter() - t0) * 1e3
-    eng.set_problem(Xi.mean(axis=0), N_ds.astype(np.float64), idx, y, beta, LB, "seir4")
+    eng.set_problem(pb["mu"], pb["N_ds"], pb["idx"], pb["y"], pb["beta"], pb["LB"], "seir4")
 
-    total = a.burnin + a.warmup + a.steps
+    # (head room behind the timed steps: the in-sampler kernel-duration leg continues the same chains for a few hundred slots)
+    head = 8
     # stale_cache=0: the reference's annealed kernel reuses the previous step's cached target, which
     # was computed at the previous temperature (SURVEY section 7 quirk ii); on this synthetic grid the
     # log posterior is positive, which makes that offset reject every proposal, so the bench runs
     # the recomputing variant (same arithmetic per leapfrog, see DESIGN.md "stale cache").
-    cfg = eng.default_cfg(num_results=a.warmup + a.steps, num_burnin_steps=a.burnin, stale_cache=0)
+    cfg = eng.default_cfg(num_results=a.warmup + a.steps + head, num_burnin_steps=a.burnin, stale_cache=0)
     rep = lambda v: np.repeat(np.asarray(v)[None], cpg, axis=0)
-    from magi_v2_amd.shard import chain_ids_for_rank
     unit_ids = chain_ids_for_rank(rank, world, cpg * world)              # which (dataset, chain) units this rank owns
     chain_ids = list(range(cpg)) if a.replicate_chains else unit_ids     # the Philox streams they are sampled with
-    eng.sampler_init(cfg, rep(Xhat), rep(sig_pre0), rep(th_pre0), seed=a.seed, chain_ids=chain_ids)
+    eng.sampler_init(cfg, rep(pb["Xhat"]), rep(pb["sig_pre0"]), rep(pb["th_pre0"]), seed=a.seed, chain_ids=chain_ids)
     eng.sampler_run(a.burnin)
     if a.warmup > 0:
         eng.sampler_run(a.warmup)
@@ -122,6 +167,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    slots_issued, graphs = eng.sampler_run_stats()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     lfs = torch.tensor([float(lf)], dtype=torch.float64, device=red_dev)
     if world > 1:
@@ -131,15 +177,15 @@ def main():
     lf_total = float(lfs.item())
 
     # ---- final sample gather over RCCL (the only collective of the job) -------------------------------
-    from magi_v2_amd.shard import gather_samples
     Xs, sp, tp = eng.sampler_samples()
-    flat = np.concatenate([Xs.reshape(cpg, Xs.shape[1], -1), sp, tp], axis=2)     # [chains, results, N*D + D + P]
+    keep = a.warmup + a.steps                                              # (the head-room rows behind them were never sampled)
+    flat = np.concatenate([Xs.reshape(cpg, Xs.shape[1], -1), sp, tp], axis=2)[:, :keep]     # [chains, results, N*D + D + P]
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     allsamp, gids = gather_samples(flat, unit_ids, dst=0)
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - t1) * 1e3 if world > 1 else 0.0
-    th_all = allsamp[:, :, -P:] if rank == 0 else None
+    th_all = allsamp[:, a.warmup:, -P:] if rank == 0 else None
 
     if rank != 0:
         if world > 1:
@@ -149,81 +195,75 @@ def main():
     n_chains = cpg * world
     value = n_chains * a.steps / elapsed
     diag = eng.sampler_diag()
-    post = diag.tree_depth[:, a.burnin + a.warmup:]
+    post = diag.tree_depth[:, a.burnin + a.warmup:a.burnin + a.warmup + a.steps]
+    lf_rank0 = float(lf)
+    state = eng.sampler_state()          # before the profiling / timing launches clobber it
 
-    state = eng.sampler_state() if (world == 1 and not a.no_cpu_baseline) else None   # before the timing launches clobber it
-
-    # ---- the same chains under round 1's protocol (40 untimed burn-in transitions): continuity with BENCH_r01 ----
-    r1 = None
-    if a.burnin != 40:
-        c40 = eng.default_cfg(num_results=a.warmup + a.steps, num_burnin_steps=40, stale_cache=0)
-        eng.sampler_init(c40, rep(Xhat), rep(sig_pre0), rep(th_pre0), seed=a.seed, chain_ids=chain_ids)
-        eng.sampler_run(40 + a.warmup)
-        torch.cuda.synchronize()
-        tr0 = time.perf_counter()
-        rlf, _ = eng.sampler_run(a.steps)
-        torch.cuda.synchronize()
-        r1s = time.perf_counter() - tr0
-        r1 = {"burnin_untimed": 40, "samples_per_s": round(cpg * a.steps / r1s, 2), "leapfrogs_per_s": round(rlf / r1s, 1),
-              "leapfrogs_per_sample": round(rlf / (cpg * a.steps), 1), "scope": "rank 0",
-              "note": "after 40 steps dual averaging is still ramping (step size about half its adapted value): not the sampler's steady state"}
+    # ---- in-sampler kernel durations (HIP events attached to every launch of the streaming kernel and of k_point: the kernels'
+    #      own begin / end stamps, decisions riding along, on the chains the timed region just ran) ----
+    st_us, pt_us, prof_lf = eng.sampler_profile(a.profile_slots)
 
     # ---- fixed-L HMC (L = 32, step size from a 100-step dual-averaging warm-up), SURVEY 8d: reported next to NUTS ----
-    hcfg = eng.default_cfg(num_results=a.steps, num_burnin_steps=100, stale_cache=0, mode=1, hmc_leapfrogs=32)
-    eng.sampler_init(hcfg, rep(Xhat), rep(sig_pre0), rep(th_pre0), seed=a.seed, chain_ids=chain_ids)
+    hsteps = min(a.steps, 50)
+    hcfg = eng.default_cfg(num_results=hsteps, num_burnin_steps=100, stale_cache=0, mode=1, hmc_leapfrogs=32)
+    eng.sampler_init(hcfg, rep(pb["Xhat"]), rep(pb["sig_pre0"]), rep(pb["th_pre0"]), seed=a.seed, chain_ids=chain_ids)
     eng.sampler_run(100)
     torch.cuda.synchronize()
     th0 = time.perf_counter()
-    hlf, _ = eng.sampler_run(a.steps)
+    hlf, _ = eng.sampler_run(hsteps)
     torch.cuda.synchronize()
     hmc_s = time.perf_counter() - th0
     hd = eng.sampler_diag()
-    hmc = {"samples_per_s": round(cpg * a.steps / hmc_s, 2), "leapfrogs_per_s": round(hlf / hmc_s, 1), "L": 32,
+    hmc = {"samples_per_s": round(cpg * hsteps / hmc_s, 2), "leapfrogs_per_s": round(hlf / hmc_s, 1), "L": 32,
            "accept_rate": round(float(hd.is_accepted[:, 100:].mean()), 3), "step_size": float(hd.step_size[0, -1]), "scope": "rank 0"}
 
-    # ---- roofline of the dominant kernel (k_stream), HIP events on the engine's stream -----------------
+    # ---- roofline of the dominant kernel (the streaming kernel) -------------------------------------------------
+    # `achieved` / `frac`: SURVEY 8d's ALGORITHMIC bytes of one gradient evaluation (3 D N W 8 + C 10 N D 8) over the kernel's
+    # mean IN-SAMPLER launch duration (st_us above; profiles/ holds the rocprofv3 kernel trace of this command, whose mean for
+    # the same kernel must agree).  The kernel itself streams fewer bytes -- the symmetric operators FH and FK are stored as
+    # their lower block triangle and FE serves both FE xc and FE^T f, about 2 N^2 D values instead of 3 (bytes_per_launch) --
+    # which is why `frac` can approach or exceed 1; frac_bytes_moved prices the bytes actually moved against the same peak,
+    # frac_of_ceiling against a load-only pass over the same blocks timed in this run; slot_frac is the per-leapfrog view.
     grad_ms, phase_ms = eng.time_gradient(cpg, 300)
     phase_bytes = eng.gradient_bytes(cpg)
-    # "achieved" / "frac" are SURVEY 8d's contract: the ALGORITHMIC bytes of one gradient (3 D N W 8 + C 10 N D 8) over the
-    # kernel's launch time.  The kernel itself streams fewer bytes: the symmetric operators FH and FK are stored as their
-    # lower block triangle and FE serves both FE xc and FE^T f -- about 2 N^2 D values instead of 3 (bytes_per_launch).
-    # frac_bytes_moved prices those bytes against the same peak; ceiling_GBps is a load-only pass over the same blocks with
-    # the same access pattern, timed here; slot_frac is the per-leapfrog view (algorithmic bytes over the whole slot
-    # [k_stream, k_point] as the sampler ran it in the timed region).
     W = N if band is None or 6 * band + 1 >= N else 2 * band + 1
     algorithmic = 3.0 * D * N * W * 8.0 + cpg * 10.0 * N * D * 8.0
-    t_stream = phase_ms[4] * 1e-3
-    achieved = algorithmic / t_stream / 1e9
-    slot_s = elapsed / (lf_total / n_chains)                                 # seconds per leapfrog slot (one leapfrog of every chain on the GPU)
+    t_stream = st_us * 1e-6
+    t_alone = phase_ms[4] * 1e-3
+    slot_s = elapsed / max(slots_issued, 1) if world == 1 else elapsed / (lf_total / n_chains)
     n_tasks = phase_bytes[4] / (128 * 128 * 8.0 + 2.0 * cpg * 128 * 8.0)     # packed 128 x 128 blocks (magi_gradient_bytes)
     tiles_bytes = n_tasks * 128 * 128 * 8.0
-    roofline = {"bound": "hbm", "kernel": "k_stream (single-phase block mat-vecs FH xc, FE xc, FE^T f, FK f over packed 128x128 blocks)",
-                "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
-                "traffic": None, "algorithmic_bytes_per_launch": algorithmic, "bytes_per_launch": phase_bytes[4],
+    ceiling = tiles_bytes / (phase_ms[7] * 1e-3) / 1e9
+    roofline = {"bound": "hbm",
+                "kernel": ("k_stream" if cpg <= 2 else "k_stream_mc") + " (single-phase block mat-vecs FH xc, FE xc, FE^T f, FK f over packed 128x128 blocks)",
+                "achieved": round(algorithmic / t_stream / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(algorithmic / t_stream / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac_basis": "SURVEY 8d algorithmic bytes / mean in-sampler launch duration of the kernel (HIP events on every launch over "
+                              f"{a.profile_slots} slots of the timed chains)",
+                "us_per_launch": round(st_us, 3), "us_per_launch_point": round(pt_us, 3),
+                "algorithmic_bytes_per_launch": algorithmic, "bytes_per_launch": phase_bytes[4],
                 "streamed_GBps": round(phase_bytes[4] / t_stream / 1e9, 1),
-                "frac_bytes_moved": round(phase_bytes[4] / t_stream / 1e9 / 8000.0, 4),
-                "ceiling_GBps": round(tiles_bytes / (phase_ms[7] * 1e-3) / 1e9, 1),
-                "ceiling_note": "load-only kernel over the same packed blocks, same 16-B-per-lane pattern and the same alternating walk, "
-                                "timed in this run; frac_of_ceiling = streamed_GBps / ceiling_GBps",
-                "frac_of_ceiling": round((phase_bytes[4] / t_stream) / (tiles_bytes / (phase_ms[7] * 1e-3)), 4),
-                "slot_frac": round(algorithmic / slot_s / 1e9 / 8000.0, 4),
-                "slot_frac_bytes_moved": round((phase_bytes[4] + phase_bytes[6]) / slot_s / 1e9 / 8000.0, 4),
-                "working_set": f"{phase_bytes[4] / 1e6:.1f} MB of operator blocks per launch: " +
-                               ("resident in the 256 MiB Infinity Cache between launches, and -- odd slots walk the blocks backwards -- the "
-                                "tail of one launch is still in the 8 x 4 MiB L2s for the head of the next: the HBM peak is the contract's "
-                                "yardstick, not the physical source of the bytes (frac may exceed what HBM alone could deliver)"
-                                if phase_bytes[4] < 200e6 else "larger than the 256 MiB Infinity Cache: streamed from HBM"),
-                "us_per_launch": round(phase_ms[4] * 1e3, 3),
-                "kernels_us": dict(zip(["phase1", "phase2", "phase3", "reduce", "stream", "leap_reduce", "point", "read_only"], [round(x * 1e3, 3) for x in phase_ms[:8]])),
-                "three_phase_gradient_eval_us": round(grad_ms * 1e3, 3)}
+                "frac_bytes_moved": round(phase_bytes[4] / t_stream / 1e9 / HBM_PEAK_GBPS, 4),
+                "ceiling_GBps": round(ceiling, 1),
+                "frac_of_ceiling": round((phase_bytes[4] / t_stream / 1e9) / ceiling, 4),
+                "slot_frac": round(algorithmic / slot_s / 1e9 / HBM_PEAK_GBPS, 4),
+                "slot_frac_bytes_moved": round((phase_bytes[4] + phase_bytes[6]) / slot_s / 1e9 / HBM_PEAK_GBPS, 4),
+                # the same kernel launched back to back WITHOUT its decision workgroups (round-1/2 definition of `frac`)
+                "standalone_us_per_launch": round(phase_ms[4] * 1e3, 3),
+                "standalone_frac": round(algorithmic / t_alone / 1e9 / HBM_PEAK_GBPS, 4),
+                "standalone_point_us": round(phase_ms[6] * 1e3, 3), "read_only_us": round(phase_ms[7] * 1e3, 3),
+                "three_phase_gradient_eval_us": round(grad_ms * 1e3, 3),
+                "working_set_MB": round(phase_bytes[4] / 1e6, 1),
+                "working_set": ("operator blocks resident in the 256 MiB Infinity Cache between launches: the HBM peak is the contract's yardstick, "
+                                "not the physical source of the bytes" if phase_bytes[4] < 200e6 else "larger than the 256 MiB Infinity Cache: streamed from HBM")}
 
     # measured memory-side traffic of the same kernel on the same workload, from the committed PMC passes
     # (rocprofv3 cannot run inside the timed process; profiles/README.md has the commands)
     try:
         import csv
         if N == 1024 and cpg == 1 and (band is None or 6 * band + 1 >= N):
-            prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            name = next(f for f in ("r02_bench_pmc_traffic.csv", "r01_bench_pmc_traffic.csv") if os.path.exists(os.path.join(prof, f)))
+            prof = os.path.join(ROOT, "profiles")
+            name = next(f for f in ("r03_bench_pmc_traffic.csv", "r02_bench_pmc_traffic.csv", "r01_bench_pmc_traffic.csv") if os.path.exists(os.path.join(prof, f)))
             with open(os.path.join(prof, name)) as fh:
                 tr = sum(float(r["bytes_per_launch_corrected"]) for r in csv.DictReader(fh) if "k_stream<1, 1>" in r["Kernel_Name"])
             if tr > 0:
@@ -236,25 +276,20 @@ def main():
     #      the reference), timed at several thread counts on this host; samples/s = gradient evaluations/s over the leapfrogs
     #      per sample the GPU chain needed in the timed region.  Second leg: the numpy oracle continuing the SAME chain. ----
     cpu = None
+    ncpu = os.cpu_count() or 1
+    threads = sorted({min(ncpu, ncpu if t == "all" else int(t)) for t in a.cpu_threads.split(",")})
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu_model = next(l.split(":", 1)[1].strip() for l in fh if l.startswith("model name"))
+    except (OSError, StopIteration):
+        cpu_model = "unknown"
+    lf_per_sample = lf_total / (n_chains * a.steps)
     if world == 1 and not a.no_cpu_baseline:
         from oracle import magi_oracle as orc
-        from oracle import torch_cpu
         import threadpoolctl
-        C_inv, m, K_inv = mats
-        pr = orc.Problem(I=I, mu=Xi.mean(axis=0), C_inv=orc.band_part(C_inv, band), m=orc.band_part(m, band),
-                         K_inv=orc.band_part(K_inv, band), N_ds=N_ds.astype(np.float64), obs_idx=idx, y=y, beta=float(beta),
-                         LB=LB, drift="seir4", P=P)
         Xc, spc, tpc, ss, bc = state
-        ncpu = os.cpu_count() or 1
-        threads = sorted({min(ncpu, ncpu if t == "all" else int(t)) for t in a.cpu_threads.split(",")})
-        lf_per_sample = lf_total / (n_chains * a.steps)
-        rates = torch_cpu.time_gradients(pr, Xc[0], spc[0], tpc[0], threads, min_evals=200, max_seconds=6.0)
+        pr, rates = cpu_gradient_rates(pb, mats, band, "seir4", P, (Xc[0], spc[0], tpc[0]), threads, 6.0)
         best_t = max(rates, key=rates.get)
-        try:
-            with open("/proc/cpuinfo") as fh:
-                cpu_model = next(l.split(":", 1)[1].strip() for l in fh if l.startswith("model name"))
-        except (OSError, StopIteration):
-            cpu_model = "unknown"
         cpu = {"value": round(rates[best_t] / lf_per_sample, 5), "unit": "samples/s", "cores": best_t, "kind": "port",
                "sample": f">= 200 value+gradient evaluations (or 6 s) per thread count of oracle/torch_cpu.py -- torch-CPU fp64 bmm + autograd "
                          f"restatement of magi_v2.py:308-348 -- at the GPU chain's state; converted with the {lf_per_sample:.1f} leapfrogs per "
@@ -265,7 +300,7 @@ def main():
         q = orc.pack(Xc[0], spc[0], tpc[0])
         fn_L = orc.make_fn_L(pr)
         L, gL = fn_L(q)
-        k = total
+        k = a.burnin + a.warmup + a.steps
         tc0 = time.perf_counter()
         n_lf = 0
         for s_ in range(a.cpu_steps):
@@ -279,6 +314,13 @@ def main():
         cpu["numpy_nuts_leg"] = {"samples_per_s": round(a.cpu_steps / cpu_s, 5), "leapfrogs_per_s": round(n_lf / cpu_s, 2), "threads": nthreads,
                                  "sample": f"{a.cpu_steps} NUTS transitions ({n_lf} leapfrogs) of the same chain continued from the GPU state by "
                                            "oracle/magi_oracle.py (numpy + OpenBLAS; streams six matrices per gradient, batched matmul does not thread)"}
+        del pr
+
+    # ---- the other BASELINE configs on this one GPU (flat scalars inside `roofline`: the driver keeps scalars only) ----
+    extra_note = None
+    if world == 1 and not a.no_extra_configs and N == 1024 and cpg == 1 and band is None:
+        extra_note = extra_configs(a, eng, host, MagiEngine, pb, roofline, threads, dev_index)
+    eng.close()
 
     out = {
         "metric": "HMC samples/sec (whole node) on SEIR, N grid pts x D comps",
@@ -287,10 +329,12 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"SEIR N={N} x 4 components, {'dense' if band is None else 'band ' + str(band)}, "
                                f"NUTS(max depth 10)+dual averaging+log annealing, {cpg} chain(s)/GPU",
+                   "baseline_config": ("BASELINE configs[1] (SEIR N=1024 x 4, 1 chain, 1 GPU)" if cpg == 1 and world == 1 else
+                                       f"weak scaling of BASELINE configs[1]: one chain per GPU x {world} GPUs" if cpg == 1 else
+                                       f"BASELINE configs[2] ({cpg * world} independent chains, {cpg} per GPU x {world} GPUs)"),
                    "grid": N, "components": D, "thetas": P, "chains_total": n_chains, "bandsize": band,
                    "burnin_untimed": a.burnin,
-                   "burnin_note": "untimed transitions that adapt the step size before the timed region (the reference burns in 1000); "
-                                  "round 1 used 40, see round1_protocol for that figure on the same chains and DESIGN.md section 5",
+                   "burnin_note": "untimed transitions that adapt the step size before the timed region (the reference burns in 1000): DESIGN.md section 5",
                    "parallelism": f"chains x{world}",
                    "stale_cache": 0, "stale_cache_note": "the reference's annealed kernel reuses the previous step's cached target (computed at the "
                                    "previous temperature); on this synthetic grid that offset rejects every proposal, so the bench recomputes at "
@@ -298,16 +342,138 @@ def main():
                    "chain_streams": "DIAGNOSTIC: every rank replicates rank 0's chain ids" if a.replicate_chains else
                                     "independent: Philox stream = global chain id (rank * chains_per_gpu + local index)"},
         "roofline": roofline, "cpu_baseline": cpu,
-        "leapfrogs_per_s": round(lf_total / elapsed, 1), "us_per_leapfrog_slot": round(elapsed / (lf_total / n_chains) * 1e6, 2),
+        "leapfrogs_per_s": round(lf_total / elapsed, 1),
+        "leapfrogs_per_s_per_gpu": round(lf_total / elapsed / world, 1),
+        "us_per_leapfrog_slot": round(elapsed / (lf_total / n_chains) * 1e6, 2),
+        "us_per_slot_issued": round(elapsed / max(slots_issued, 1) * 1e6, 3), "slots_issued_rank0": int(slots_issued),
+        "slot_overhead_rank0": round(slots_issued / max(float(diag.leapfrogs_taken[:, a.burnin + a.warmup:a.burnin + a.warmup + a.steps].sum(axis=1).max()), 1.0), 4),
+        "slot_note": "us_per_leapfrog_slot = elapsed / (leapfrogs per chain, mean); us_per_slot_issued = elapsed / kernel pairs [stream, point] "
+                     "actually issued on rank 0 (device counter); slot_overhead = slots issued / leapfrogs of the busiest chain (skip / set-up slots)",
         "mean_tree_depth": round(float(post.mean()), 2), "device_ms": round(dev_ms, 2), "build_ms": round(build_ms, 1),
-        "leapfrogs_per_sample": round(lf_total / (n_chains * a.steps), 1),
-        "gather_ms": round(gather_ms, 3), "hmc_L32": hmc, "round1_protocol": r1, "theta_mean": [round(float(x), 4) for x in np.log1p(np.exp(th_all)).reshape(-1, P).mean(axis=0)],
+        "leapfrogs_per_sample": round(lf_per_sample, 1),
+        "gather_ms": round(gather_ms, 3), "hmc_L32": hmc,
+        "theta_mean": [round(float(x), 4) for x in np.log1p(np.exp(th_all)).reshape(-1, P).mean(axis=0)],
     }
+    if n_chains <= 64:       # what the final gather delivered: global unit ids in order, and each chain's last theta (distinct chains differ)
+        out["gathered_unit_ids"] = [int(g_) for g_ in gids]
+        out["theta_last_per_chain"] = [[round(float(x), 10) for x in np.log1p(np.exp(th_all[c, -1]))] for c in range(n_chains)]
+    if extra_note:
+        out["extra_configs"] = extra_note
     if cpu:
         out["speedup_vs_cpu_port"] = round(value / cpu["value"], 1)          # against the BEST thread count of the torch-CPU leg
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def extra_configs(a, eng, host, MagiEngine, pb2, roofline, threads, dev_index):
+    """BASELINE configs 1, 3 (per-GPU share), 4 (one dataset) and 5 on the same GPU, after the headline region.  Results go into
+    `roofline` as flat scalars; returns a short description of what was run."""
+    D, P = 4, 3
+    note = {}
+    rep8 = lambda v: np.repeat(np.asarray(v)[None], 8, axis=0)
+
+    # ---- config 3's per-GPU share: 8 independent chains at N = 1024 (global ids 0..7 = rank 0 of 8) ----
+    steps3 = 50
+    cfg3 = eng.default_cfg(num_results=steps3 + 3 + 8, num_burnin_steps=a.burnin, stale_cache=0)
+    el, lf3, dev_ms, slots = timed_run(eng, cfg3, pb2, 8, list(range(8)), a.seed, a.burnin, 3, steps3)
+    st_us, pt_us, _ = eng.sampler_profile(a.profile_slots)
+    pbytes = eng.gradient_bytes(8)
+    alg8 = 3.0 * D * 1024 * 1024 * 8.0 + 8 * 10.0 * 1024 * D * 8.0
+    _, ph8 = eng.time_gradient(8, 200)
+    roofline.update({
+        "mc8_samples_per_s": round(8 * steps3 / el, 2), "mc8_leapfrogs_per_s": round(lf3 / el, 1),
+        "mc8_us_per_slot": round(el / max(slots, 1) * 1e6, 3), "mc8_slots_issued": int(slots),
+        "mc8_stream_us": round(st_us, 3), "mc8_point_us": round(pt_us, 3), "mc8_stream_us_standalone": round(ph8[4] * 1e3, 3),
+        "mc8_frac": round(alg8 / (st_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+        "mc8_frac_bytes_moved": round(pbytes[4] / (st_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+        "mc8_frac_of_ceiling": round(ph8[7] * 1e3 / st_us, 4),
+        "mc8_mfma_frac": round(8 * 8.0 * D * 1024 * 1024 / (st_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+        "mc8_timed_transitions": steps3})
+    note["config3_share"] = f"8 chains (ids 0..7), N=1024 x 4 dense, {a.burnin} untimed burn-in + 3 warm-up, {steps3} timed NUTS transitions; k_stream_mc durations from {a.profile_slots} event-timed slots"
+
+    # ---- config 1: SEIR-4, N = 161 (81 thinned rows of data/SEIR_seed=0.csv, discretization 1), b = 80, 1 chain, 200 + 200 ----
+    g3 = np.load(os.path.join(ROOT, "tests", "golden", "g3_pipeline.npz"))
+    I1 = g3["seir4_I"][:, 0]
+    X1 = g3["seir4_X_obs_discret"]
+    pb1 = setup_problem(host, I1, X1, P)
+    e1 = MagiEngine(dev_index)
+    mats1 = e1.build_matrices(I1, pb1["hp"]["phi1s"], pb1["hp"]["phi2s"], 2.01, bandsize=80, want_host=not a.no_cpu_baseline)
+    e1.set_problem(pb1["mu"], pb1["N_ds"], pb1["idx"], pb1["y"], pb1["beta"], pb1["LB"], "seir4")
+    cfg1 = e1.default_cfg(num_results=200, num_burnin_steps=200)           # reference defaults (stale cache as the reference)
+    el1, lf1, _, slots1 = timed_run(e1, cfg1, pb1, 1, [0], a.seed, 200, 0, 200)
+    roofline.update({"cfg1_samples_per_s": round(200 / el1, 2), "cfg1_leapfrogs_per_s": round(lf1 / el1, 1),
+                     "cfg1_us_per_slot": round(el1 / max(slots1, 1) * 1e6, 3), "cfg1_leapfrogs_per_sample": round(lf1 / 200, 1)})
+    if not a.no_cpu_baseline:
+        st = e1.sampler_state()
+        _, r1 = cpu_gradient_rates(pb1, mats1, 80, "seir4", P, (st[0][0], st[1][0], st[2][0]), [t for t in threads if t <= 8] or [1], 3.0)
+        bt = max(r1, key=r1.get)
+        roofline.update({"cfg1_cpu_samples_per_s": round(r1[bt] / max(lf1 / 200, 1e-9), 3), "cfg1_cpu_cores": bt,
+                         "cfg1_cpu_gradient_evals_per_s": round(r1[bt], 1),
+                         "cfg1_speedup_vs_cpu_port": round((200 / el1) / (r1[bt] / max(lf1 / 200, 1e-9)), 1)})
+    note["config1"] = "SEIR-4 N=161 (tests/golden/g3_pipeline.npz: the vignette thinning of data/SEIR_seed=0.csv), b=80, 1 chain, 200 burn-in + 200 timed NUTS samples, reference defaults; CPU: torch-CPU gradient rate / leapfrogs per sample"
+
+    # ---- config 4: one dataset of the alpha sweep (alpha = 0.15, seed 0) x 8 chains, N = 161, b = 80 ----
+    sweep = np.load(os.path.join(ROOT, "tests", "golden", "seir_alpha_sweep.npz"))
+    rows = sweep["alpha=0.15_seed=0"]
+    I4, X4 = host.discretize(rows[:, 0], np.clip(rows[:, 1:5], 0.0, None), 1)
+    pb4 = setup_problem(host, np.asarray(I4).reshape(-1), X4, P)
+    e1.build_matrices(pb4["I"], pb4["hp"]["phi1s"], pb4["hp"]["phi2s"], 2.01, bandsize=80, want_host=False)
+    e1.set_problem(pb4["mu"], pb4["N_ds"], pb4["idx"], pb4["y"], pb4["beta"], pb4["LB"], "seir4")
+    cfg4 = e1.default_cfg(num_results=100, num_burnin_steps=200)
+    el4, lf4, _, slots4 = timed_run(e1, cfg4, pb4, 8, list(range(8)), a.seed, 200, 0, 100)
+    roofline.update({"cfg4_samples_per_s": round(8 * 100 / el4, 2), "cfg4_leapfrogs_per_s": round(lf4 / el4, 1),
+                     "cfg4_us_per_slot": round(el4 / max(slots4, 1) * 1e6, 3)})
+    note["config4_unit"] = "one dataset (alpha=0.15, seed 0; tests/golden/seir_alpha_sweep.npz) x 8 chains, N=161, b=80, 200 burn-in + 100 timed samples per chain"
+    e1.close()
+
+    # ---- config 5: N = 8192 x 4 -- one pooled build (wall time), one build with per-class device times, the streaming kernel ----
+    N5 = 8192
+    I5, X5, _, _ = host.synthetic_seir(N5, seed=0)
+    pb5 = setup_problem(host, I5, X5, P)
+    e5 = MagiEngine(dev_index)
+    e5.build_matrices(I5, pb5["hp"]["phi1s"], pb5["hp"]["phi2s"], 2.01, want_host=False)          # (allocates the pooled work space)
+    torch.cuda.synchronize()
+    tb = time.perf_counter()
+    e5.build_matrices(I5, pb5["hp"]["phi1s"], pb5["hp"]["phi2s"], 2.01, want_host=False)
+    build_s = time.perf_counter() - tb
+    os.environ["MAGI_BUILD_PROFILE"] = "1"
+    try:
+        e5.build_matrices(I5, pb5["hp"]["phi1s"], pb5["hp"]["phi2s"], 2.01, want_host=False)
+        prof = e5.build_profile()
+    finally:
+        del os.environ["MAGI_BUILD_PROFILE"]
+    fl = lambda k: prof[k][0]
+    ms = lambda k: prof[k][1]
+    potrf_ms = ms("diag_chol_inv") + ms("potrf_panel") + ms("potrf_trailing_syrk")
+    potrf_flop = 8 * N5 ** 3 / 3.0                                  # two factorisations (Kappa, K_d) x 4 components, N^3 / 3 each
+    alg = 5.0 * N5 ** 3 * D                                         # SURVEY 8a2: chol x2, TRSM x2, SYRK, POTRI x2 per component
+    issued = sum(v[0] for v in prof.values())
+    prod_ms = ms("m_K_products")
+    roofline.update({
+        "n8192_build_s": round(build_s, 4), "n8192_build_frac": round(alg / build_s / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+        "n8192_potrf_ms": round(potrf_ms, 2), "n8192_potrf_frac": round(potrf_flop / (potrf_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+        "n8192_products_ms": round(prod_ms, 2), "n8192_products_frac": round(fl("m_K_products") / (prod_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+        "n8192_operators_frac": round(fl("single_phase_operators") / (ms("single_phase_operators") * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+        "n8192_trtri_frac": round(fl("trtri") / (ms("trtri") * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+        "n8192_TtT_frac": round(fl("TtT") / (ms("TtT") * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+        "n8192_diag_ms": round(ms("diag_chol_inv"), 2), "n8192_rank_k_ms": round(ms("potrf_trailing_syrk"), 2), "n8192_panel_ms": round(ms("potrf_panel"), 2),
+        "n8192_matern_ms": round(ms("matern"), 2),
+        "n8192_issued_over_algorithmic": round(issued / alg, 3), "n8192_profiled_build_ms": round(sum(v[1] for v in prof.values()), 1)})
+    e5.set_problem(pb5["mu"], pb5["N_ds"], pb5["idx"], pb5["y"], pb5["beta"], pb5["LB"], "seir4")
+    lp5, *_ = e5.logpost_grad(pb5["Xhat"], pb5["sig_pre0"], pb5["th_pre0"], 1.0, fused=True)        # (loads a state for the timing launches)
+    _, ph5 = e5.time_gradient(1, 20)
+    b5 = e5.gradient_bytes(1)
+    roofline.update({"n8192_stream_us": round(ph5[4] * 1e3, 1), "n8192_stream_GB": round(b5[4] / 1e9, 3),
+                     "n8192_stream_frac_bytes_moved": round(b5[4] / (ph5[4] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "n8192_stream_frac": round(b5[7] / (ph5[4] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "n8192_read_only_frac": round((b5[4] - 2.0 * 128 * 8 * (b5[4] / (128 * 128 * 8.0 + 2.0 * 128 * 8.0))) / (ph5[7] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "n8192_logpost_finite": bool(np.isfinite(lp5))})
+    note["config5"] = ("N=8192 x 4 dense: second pooled build timed on the host clock (n8192_build_s; 5 N^3 D algorithmic flops), a third build with "
+                       "MAGI_BUILD_PROFILE=1 for the per-class device times (serialised: HIP events around every launch), then the streaming kernel "
+                       "on the 4.4 GB of operator blocks (standalone, 20 launches: nothing is cache-resident at this size)")
+    e5.close()
+    return note
 
 
 if __name__ == "__main__":

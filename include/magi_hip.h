@@ -198,6 +198,18 @@ int magi_sampler_get_diag(magi_handle* h, double* step_size, double* log_accept_
 int magi_sampler_get_state(magi_handle* h, double* X, double* sig_pre, double* th_pre,
                            double* step_size, double* beta_cache);
 
+/* Checkpoint / resume (the reference has none: a run is all-or-nothing, magi_v2.py:386-425).  Between two magi_sampler_run
+ * calls every chain stands at a transition boundary; its state is (X, sig_pre, th_pre) from magi_sampler_get_state plus
+ * MAGI_CKPT_SCALARS doubles per chain from magi_sampler_get_checkpoint (transition index, dual-averaging state, cached
+ * temperature, leapfrog count).  To resume -- in this or another process / handle: magi_sampler_init with the SAME cfg, seed
+ * and chain_ids and the checkpointed states, then magi_sampler_set_checkpoint(scalars), then magi_sampler_run: the remaining
+ * transitions are those the uninterrupted run would have made, bit for bit (the Philox streams are keyed by transition index
+ * and chain id; target and gradient of the restored state are re-evaluated by the same kernels).  Samples and diagnostics of
+ * the steps taken before the checkpoint belong to the run that took them. */
+#define MAGI_CKPT_SCALARS 16
+int magi_sampler_get_checkpoint(magi_handle* h, double* scalars /* [n_chains][MAGI_CKPT_SCALARS] */);
+int magi_sampler_set_checkpoint(magi_handle* h, const double* scalars /* [n_chains][MAGI_CKPT_SCALARS] */);
+
 /* One-call form: init + run(num_burnin + num_results) + get_samples. */
 int magi_sample(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains,
                 const double* X0, const double* sig_pre0, const double* th_pre0,
@@ -214,6 +226,18 @@ int magi_sample(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains,
  * memory system offers k_stream for this layout and working set), measured in separate event-bracketed loops.  Uses the states currently on the
  * device (n_chains as last set). */
 int magi_time_gradient(magi_handle* h, int n_chains, int reps, double* total_ms_per_eval, double* phase_ms);
+
+/* Of the last magi_sampler_run: leapfrog slots (kernel pairs [k_stream, k_point]) issued before every chain had finished --
+ * counted on the device -- and graph launches (of 64 slots each) the host made.  A slot advances every unfinished chain by one
+ * leaf or one set-up step, so slots_issued >= the leapfrogs of the busiest chain. */
+int magi_sampler_run_stats(magi_handle* h, int64_t* slots_issued, int64_t* graphs_launched);
+
+/* In-sampler kernel durations: continues the chains for n_slots leapfrog slots launched one by one (no graph) with HIP events
+ * attached to every launch (hipExtLaunchKernel start / stop events = the kernel's own begin / end time stamps, the quantity
+ * rocprofv3 --kernel-trace reports), decisions riding along as in production.  stream_us / point_us = mean device time per
+ * launch of the streaming kernel and of k_point; leapfrogs_done = gradient evaluations taken (sum over chains).  The chains are
+ * left inside a transition: the sampler must be re-initialised afterwards (MAGI_E_STATE otherwise). */
+int magi_sampler_profile(magi_handle* h, int n_slots, double* stream_us, double* point_us, int64_t* leapfrogs_done);
 
 /* phase_bytes[8]: bytes each of those seven kernels must move per launch for the current matrices
  * and n_chains; [7] = the algorithmic bytes of one gradient evaluation as

@@ -867,7 +867,10 @@ int launch_gemm(magi_handle* h, hipStream_t s, const GemmArgs& g_in, int batch =
     if (g.M <= 0 || g.N <= 0 || batch <= 0) return MAGI_OK;
     const int tY = (g.M + GT - 1) / GT, tX = (g.N + GT - 1) / GT, sY = (tY + 7) / 8, sX = (tX + 7) / 8;
     const int nsuper = g.lower_only ? sY * (sY + 1) / 2 : sY * sX;           // (lower-only: square tile grids)
-    static const int remap_min = [] { const char* e = getenv("MAGI_GEMM_REMAP_MIN"); return e ? atoi(e) : 24; }();
+    // (read at every launch, not cached: tests/test_fullsize_gpu.py forces the super-block order on small tile grids with
+    //  MAGI_GEMM_REMAP_MIN=1 in the same process that later runs the default)
+    const char* remap_env = getenv("MAGI_GEMM_REMAP_MIN");
+    const int remap_min = remap_env ? atoi(remap_env) : 24;
     g.remap = (nsuper >= remap_min && (!g.lower_only || tY == tX)) ? 1 : 0;
     dim3 grid(g.remap ? ((nsuper + 7) / 8) * 8 * 64 : tY * tX, 1, batch);
     prof_begin(s);
@@ -945,7 +948,8 @@ int potrf(Linalg& la, double* A, const char* what, bool defer_status = false, in
     // (Look-ahead -- the rest of a trailing update on a second stream under the next block column's diagonal / panel chain -- was
     //  measured: 347 against 345 ms at N = 8192.  The update's workgroups hold every CU's LDS, and the diagonal kernel needs 158 KB
     //  of one CU: it does not start before the update drains.)
-    static const int NPAN = [] { const char* e = getenv("MAGI_POTRF_PANELS"); const int v = e ? atoi(e) : 4; return std::max(1, std::min(v, 16)); }();
+    const char* npan_env = getenv("MAGI_POTRF_PANELS");
+    const int NPAN = std::max(1, std::min(npan_env ? atoi(npan_env) : 4, 16));
     int rc = MAGI_OK;
     for (int j0 = 0; j0 < N && rc == MAGI_OK; j0 += NPAN * NB) {
         for (int c = 0; c < NPAN && rc == MAGI_OK; ++c) {
@@ -1360,8 +1364,13 @@ int magi_ensure_dense(magi_handle* h, int N, int D) {
     for (int k = 0; k < 3; ++k) { if (h->dDense[k]) (void)hipFree(h->dDense[k]); h->dDense[k] = nullptr; }
     h->dense_N = h->dense_D = 0;
     for (int k = 0; k < 3; ++k) {
-        MAGI_HIP_CHECK(h, hipMalloc(&h->dDense[k], nn * D * sizeof(double)));
-        MAGI_HIP_CHECK(h, hipMemset(h->dDense[k], 0, nn * D * sizeof(double)));       // components never built read as zero matrices
+        hipError_t e = hipMalloc(&h->dDense[k], nn * D * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(h->dDense[k], 0, nn * D * sizeof(double));         // components never built read as zero matrices
+        if (e != hipSuccess) {       // all three or none: a partial set must not pass the callers' `dDense[0] != null` guards
+            (void)hipGetLastError();
+            for (int j = 0; j < 3; ++j) { if (h->dDense[j]) (void)hipFree(h->dDense[j]); h->dDense[j] = nullptr; }
+            return magi_fail(h, MAGI_E_HIP, std::string("dense stacks (3 x ") + std::to_string(nn * D * sizeof(double) >> 20) + " MiB): " + hipGetErrorString(e));
+        }
     }
     h->dense_N = N; h->dense_D = D;
     return MAGI_OK;

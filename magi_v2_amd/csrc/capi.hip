@@ -151,9 +151,12 @@ int magi_ensure_chains(magi_handle* h, int n) {
         MAGI_HIP_CHECK(h, hipMalloc(&h->d_fin, sizeof(double) * 8 * n));
         h->cap_chains = n;
     }
-    if (h->n_chains != n) drop_graph(h);
+    const bool fam = magi_stream_family_mc(n);
+    if (h->n_chains != n || fam != h->family_mc) drop_graph(h);
     h->n_chains = n;
     h->ch.n_chains = n;
+    h->family_mc = fam;
+    h->ch.mc = fam ? 1 : 0;
     return MAGI_OK;
 }
 
@@ -214,6 +217,7 @@ void magi_destroy(magi_handle* h) {
     if (h->ev_t0) (void)hipEventDestroy(h->ev_t0);
     if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
     if (h->h_gctl) (void)hipHostFree(h->h_gctl);
+    if (h->apply_pin) (void)hipHostFree(h->apply_pin);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -224,6 +228,8 @@ int magi_set_matrices(magi_handle* h, int N, int D, int bandsize, const double* 
     if (!C_inv || !m || !K_inv) return magi_fail(h, MAGI_E_BADARG, "null matrix pointer");
     if (N < 2 || D < 1 || D > MAGI_MAX_D) return magi_fail(h, MAGI_E_BADARG, "need N >= 2 and 1 <= D <= " + std::to_string(MAGI_MAX_D));
     (void)hipSetDevice(h->device);
+    h->have_matrices = false;          // the packed operands describe the OLD dense stacks until the pack below has succeeded
+    h->sampler_ready = false;
     const size_t bytes = (size_t)D * N * N * sizeof(double);
     int rc = magi_ensure_dense(h, N, D);
     if (rc) return rc;
@@ -249,7 +255,7 @@ int magi_build_dense(magi_handle* h, const double* I, int N, int D, int n_sel, c
 
 int magi_pack_resident(magi_handle* h, int bandsize) {
     if (!h) return MAGI_E_BADARG;
-    if (!h->dDense[0]) return magi_fail(h, MAGI_E_STATE, "no resident matrices: build or set them first");
+    if (!h->dDense[0] || h->dense_N <= 0) return magi_fail(h, MAGI_E_STATE, "no resident matrices: build or set them first");
     (void)hipSetDevice(h->device);
     int rc = magi_pack_matrices(h, h->dense_N, h->dense_D, bandsize, h->dDense[0], h->dDense[1], h->dDense[2]);
     (void)hipStreamSynchronize(h->stream);
@@ -258,7 +264,7 @@ int magi_pack_resident(magi_handle* h, int bandsize) {
 
 int magi_get_dense(magi_handle* h, int bandsize, double* C_inv, double* m, double* K_inv) {
     if (!h) return MAGI_E_BADARG;
-    if (!h->dDense[0]) return magi_fail(h, MAGI_E_STATE, "no resident matrices");
+    if (!h->dDense[0] || h->dense_N <= 0) return magi_fail(h, MAGI_E_STATE, "no resident matrices");
     (void)hipSetDevice(h->device);
     const int N = h->dense_N, D = h->dense_D;
     const size_t nn = (size_t)N * N;
@@ -279,19 +285,28 @@ int magi_get_dense(magi_handle* h, int bandsize, double* C_inv, double* m, doubl
 
 int magi_dense_apply(magi_handle* h, int which, int transpose, int nv, const double* V, double* Y) {
     if (!h) return MAGI_E_BADARG;
-    if (!h->dDense[0]) return magi_fail(h, MAGI_E_STATE, "no resident matrices");
+    if (!h->dDense[0] || h->dense_N <= 0) return magi_fail(h, MAGI_E_STATE, "no resident matrices");
     if (which < 0 || which > 2 || nv < 1 || nv > 8 || !V || !Y) return magi_fail(h, MAGI_E_BADARG, "which in 0..2, 1 <= nv <= 8, non-null vectors");
     (void)hipSetDevice(h->device);
+    // (called 2 x 10 000 times by the theta initialiser's general branch: device scratch and pinned staging are kept in the handle
+    //  -- grow-only -- and the copies ride on the handle's stream: one synchronisation per call, no allocation)
     const size_t n = (size_t)h->dense_D * h->dense_N * nv;
-    double *dV = nullptr, *dY = nullptr;
-    struct Tmp { double*& p; ~Tmp() { free_dev(p); } } t1{dV}, t2{dY};
-    MAGI_HIP_CHECK(h, hipMalloc(&dV, n * sizeof(double)));
-    MAGI_HIP_CHECK(h, hipMalloc(&dY, n * sizeof(double)));
-    MAGI_HIP_CHECK(h, hipMemcpy(dV, V, n * sizeof(double), hipMemcpyHostToDevice));
+    double* dV = magi_workspace(h, magi_handle::WS_APPLY, 2 * n);
+    if (!dV) return MAGI_E_HIP;
+    double* dY = dV + n;
+    if (2 * n > h->apply_pin_cap) {
+        if (h->apply_pin) (void)hipHostFree(h->apply_pin);
+        h->apply_pin = nullptr; h->apply_pin_cap = 0;
+        MAGI_HIP_CHECK(h, hipHostMalloc((void**)&h->apply_pin, 2 * n * sizeof(double), hipHostMallocDefault));
+        h->apply_pin_cap = 2 * n;
+    }
+    std::memcpy(h->apply_pin, V, n * sizeof(double));
+    MAGI_HIP_CHECK(h, hipMemcpyAsync(dV, h->apply_pin, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     int rc = magi_dense_apply_device(h, which, transpose, nv, dV, dY);
     if (rc) return rc;
+    MAGI_HIP_CHECK(h, hipMemcpyAsync(h->apply_pin + n, dY, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    MAGI_HIP_CHECK(h, hipMemcpy(Y, dY, n * sizeof(double), hipMemcpyDeviceToHost));
+    std::memcpy(Y, h->apply_pin + n, n * sizeof(double));
     return MAGI_OK;
 }
 
@@ -552,7 +567,8 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
     // + one set-up slot per doubling + start / end: a pump that outlives that budget means a corrupted control block
     // (+ one more set-up slot per doubling and two per transition end when a batch of NUTS chains spreads those passes: decide.h)
     const long long per_transition = (h->cfg.mode == MAGI_MODE_HMC ? (long long)h->cfg.hmc_L : (1ll << (h->cfg.max_depth + 1))) + 2 * h->cfg.max_depth + 8;
-    const long long max_graphs = ((long long)(g.stop_k - kmin) * per_transition + 8) / kGraphSlots + 4;
+    long long max_graphs = ((long long)(g.stop_k - kmin) * per_transition + 8) / kGraphSlots + 4;
+    if (const char* e = getenv("MAGI_SLOT_BUDGET_GRAPHS")) max_graphs = std::max(1ll, std::min(max_graphs, (long long)atoll(e)));    // (tests: force the budget exit)
     while (!done) {
         if (issued >= max_graphs && issued == retired) {
             (void)hipStreamSynchronize(h->stream);
@@ -585,6 +601,12 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
     }
     MAGI_HIP_CHECK(h, hipEventRecord(h->ev_t1, h->stream));
     MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    {
+        GlobalCtl gend{};
+        MAGI_HIP_CHECK(h, hipMemcpy(&gend, h->ch.gctl, sizeof(GlobalCtl), hipMemcpyDeviceToHost));
+        h->last_slots = gend.slots;
+        h->last_graphs = issued;
+    }
     if (kernel_ms) {
         float ms = 0.f;
         MAGI_HIP_CHECK(h, hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
@@ -596,6 +618,61 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
         for (auto& c : ctl) lf1 += c.total_leapfrogs;
         *leapfrogs_done = lf1 - lf0;
     }
+    return MAGI_OK;
+}
+
+int magi_sampler_run_stats(magi_handle* h, int64_t* slots_issued, int64_t* graphs_launched) {
+    if (!h) return MAGI_E_BADARG;
+    if (slots_issued) *slots_issued = h->last_slots;
+    if (graphs_launched) *graphs_launched = h->last_graphs;
+    return MAGI_OK;
+}
+
+int magi_sampler_profile(magi_handle* h, int n_slots, double* stream_us, double* point_us, int64_t* leapfrogs_done) {
+    if (!h) return MAGI_E_BADARG;
+    if (!h->sampler_ready) return magi_fail(h, MAGI_E_STATE, "sampler not initialised");
+    if (n_slots < 2 || n_slots > 65536) return magi_fail(h, MAGI_E_BADARG, "n_slots in [2, 65536]");
+    (void)hipSetDevice(h->device);
+    n_slots &= ~1;                       // slot parity 0 first, as a graph launch
+    std::vector<ChainCtl> ctl(h->n_chains);
+    MAGI_HIP_CHECK(h, hipMemcpy(ctl.data(), h->ch.ctl, sizeof(ChainCtl) * h->n_chains, hipMemcpyDeviceToHost));
+    long long lf0 = 0;
+    for (auto& c : ctl) lf0 += c.total_leapfrogs;
+    GlobalCtl g{};
+    g.n_chains = h->n_chains;
+    g.stop_k = h->cfg.total;             // run on: the chains are paused again below
+    g.epoch = ++h->epoch;
+    MAGI_HIP_CHECK(h, hipMemcpy(h->ch.gctl, &g, sizeof(GlobalCtl), hipMemcpyHostToDevice));
+    std::vector<hipEvent_t> ev((size_t)4 * n_slots, nullptr);
+    int rc = MAGI_OK;
+    for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) rc = magi_fail(h, MAGI_E_HIP, "hipEventCreate");
+    for (int sl = 0; sl < n_slots && rc == MAGI_OK; ++sl) {
+        h->prof_e0 = ev[(size_t)4 * sl]; h->prof_e1 = ev[(size_t)4 * sl + 1];
+        rc = magi_launch_stream(h, h->n_chains, sl & 1, true, h->stream);
+        h->prof_e0 = ev[(size_t)4 * sl + 2]; h->prof_e1 = ev[(size_t)4 * sl + 3];
+        if (rc == MAGI_OK) rc = magi_launch_point(h, h->n_chains, sl & 1, h->stream);
+    }
+    h->prof_e0 = h->prof_e1 = nullptr;
+    (void)hipStreamSynchronize(h->stream);
+    double ts = 0.0, tp = 0.0;
+    int ns = 0, np_ = 0;
+    for (int sl = 0; sl < n_slots && rc == MAGI_OK; ++sl) {
+        float a = 0.f, b = 0.f;
+        if (hipEventElapsedTime(&a, ev[(size_t)4 * sl], ev[(size_t)4 * sl + 1]) == hipSuccess) { ts += a; ++ns; }
+        if (hipEventElapsedTime(&b, ev[(size_t)4 * sl + 2], ev[(size_t)4 * sl + 3]) == hipSuccess) { tp += b; ++np_; }
+    }
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    (void)hipGetLastError();
+    if (rc) return rc;
+    if (stream_us) *stream_us = ns ? ts / ns * 1e3 : 0.0;
+    if (point_us) *point_us = np_ ? tp / np_ * 1e3 : 0.0;
+    MAGI_HIP_CHECK(h, hipMemcpy(ctl.data(), h->ch.ctl, sizeof(ChainCtl) * h->n_chains, hipMemcpyDeviceToHost));
+    long long lf1 = 0;
+    for (auto& c : ctl) lf1 += c.total_leapfrogs;
+    if (leapfrogs_done) *leapfrogs_done = lf1 - lf0;
+    // the chains stand somewhere inside a transition: the sampler state is no longer at a transition boundary a later
+    // magi_sampler_run could be compared against anything from -- the handle must be re-initialised
+    h->sampler_ready = false;
     return MAGI_OK;
 }
 
@@ -660,6 +737,45 @@ int magi_sampler_get_state(magi_handle* h, double* X, double* sig_pre, double* t
         if (step_size) step_size[c] = ctl[c].da_step_size;
         if (beta_cache) beta_cache[c] = ctl[c].beta_cache;
     }
+    return MAGI_OK;
+}
+
+// per-chain scalars of a checkpoint (magi_sampler_get_checkpoint / magi_sampler_set_checkpoint)
+enum { CKPT_K = 0, CKPT_DA_STEP, CKPT_STEP_SIZE, CKPT_ERR_SUM, CKPT_LOG_AVG, CKPT_LOG_SHRINK, CKPT_BETA_CACHE, CKPT_TOTAL_LF, CKPT_COUNT };
+
+int magi_sampler_get_checkpoint(magi_handle* h, double* scalars) {
+    if (!h || !scalars) return MAGI_E_BADARG;
+    if (!h->sampler_ready) return magi_fail(h, MAGI_E_STATE, "sampler not initialised");
+    (void)hipSetDevice(h->device);
+    std::vector<ChainCtl> ctl(h->n_chains);
+    MAGI_HIP_CHECK(h, hipMemcpy(ctl.data(), h->ch.ctl, sizeof(ChainCtl) * h->n_chains, hipMemcpyDeviceToHost));
+    for (int c = 0; c < h->n_chains; ++c) {
+        if (ctl[c].phase != PH_IDLE) return magi_fail(h, MAGI_E_STATE, "chain " + std::to_string(c) + " is inside a transition");
+        double* o = scalars + (size_t)c * MAGI_CKPT_SCALARS;
+        for (int k = 0; k < MAGI_CKPT_SCALARS; ++k) o[k] = 0.0;
+        o[CKPT_K] = ctl[c].k; o[CKPT_DA_STEP] = ctl[c].da_step; o[CKPT_STEP_SIZE] = ctl[c].da_step_size;
+        o[CKPT_ERR_SUM] = ctl[c].da_error_sum; o[CKPT_LOG_AVG] = ctl[c].da_log_avg; o[CKPT_LOG_SHRINK] = ctl[c].da_log_shrink;
+        o[CKPT_BETA_CACHE] = ctl[c].beta_cache; o[CKPT_TOTAL_LF] = (double)ctl[c].total_leapfrogs;
+    }
+    return MAGI_OK;
+}
+
+int magi_sampler_set_checkpoint(magi_handle* h, const double* scalars) {
+    if (!h || !scalars) return MAGI_E_BADARG;
+    if (!h->sampler_ready) return magi_fail(h, MAGI_E_STATE, "call magi_sampler_init with the checkpointed states first");
+    (void)hipSetDevice(h->device);
+    static_assert(CKPT_COUNT <= MAGI_CKPT_SCALARS, "checkpoint layout");
+    std::vector<ChainCtl> ctl(h->n_chains);
+    MAGI_HIP_CHECK(h, hipMemcpy(ctl.data(), h->ch.ctl, sizeof(ChainCtl) * h->n_chains, hipMemcpyDeviceToHost));
+    for (int c = 0; c < h->n_chains; ++c) {
+        const double* o = scalars + (size_t)c * MAGI_CKPT_SCALARS;
+        if (ctl[c].phase != PH_IDLE || ctl[c].k != 0) return magi_fail(h, MAGI_E_STATE, "set the checkpoint right after magi_sampler_init");
+        if (o[CKPT_K] < 0 || o[CKPT_K] > h->cfg.total || !(o[CKPT_STEP_SIZE] > 0.0)) return magi_fail(h, MAGI_E_BADARG, "checkpoint of chain " + std::to_string(c) + " does not fit this configuration");
+        ctl[c].k = (int)o[CKPT_K]; ctl[c].da_step = (int)o[CKPT_DA_STEP]; ctl[c].da_step_size = o[CKPT_STEP_SIZE];
+        ctl[c].da_error_sum = o[CKPT_ERR_SUM]; ctl[c].da_log_avg = o[CKPT_LOG_AVG]; ctl[c].da_log_shrink = o[CKPT_LOG_SHRINK];
+        ctl[c].beta_cache = o[CKPT_BETA_CACHE]; ctl[c].total_leapfrogs = (long long)o[CKPT_TOTAL_LF];
+    }
+    MAGI_HIP_CHECK(h, hipMemcpy(h->ch.ctl, ctl.data(), sizeof(ChainCtl) * h->n_chains, hipMemcpyHostToDevice));
     return MAGI_OK;
 }
 

@@ -138,6 +138,7 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
     reduce_prefetch_ops_load<OPS_PER>(pb, ch.vec + vec_off(pb, chain, 0), DriftT<DRIFT>::D + DriftT<DRIFT>::P, ops_v);
     __builtin_amdgcn_sched_barrier(0);
     if (all_done) return;
+    if (chain == 0 && tid == PT_THREADS - 4) __hip_atomic_fetch_add(&ch.gctl->slots, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (no return value: fire and forget)
     if (tid < (int)(sizeof(ChainCtl) / 4)) reinterpret_cast<int*>(s_ctl)[tid] = ctl_w;
     else if (tid == PT_THREADS - 2) s_g[0] = ctl_w;
     else if (tid == PT_THREADS - 1) s_g[1] = ctl_w;
@@ -488,7 +489,7 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
                     pw[e] = ph;
                     const double qn = q0[u] + eps * ph;
                     qw[e] = qn;
-                    if (ch.n_chains >= 3 && e < pb.ND) { const int dd = e / pb.N; ch.xop[xop_off(pb, ch.n_chains, parity ^ 1, chain, dd, e - dd * pb.N)] = qn; }   // (read by the next slot's stream)
+                    if (ch.mc && e < pb.ND) { const int dd = e / pb.N; ch.xop[xop_off(pb, ch.n_chains, parity ^ 1, chain, dd, e - dd * pb.N)] = qn; }   // (read by the next slot's stream)
                     v.rhosub[e] = 0.0;
                     if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par, true, s_cst + MAGI_MAX_D);
                 }

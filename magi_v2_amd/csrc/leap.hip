@@ -74,7 +74,7 @@ constexpr int ST_RW = MAGI_TB / ST_WAVES;      // rows of the block per wave
 #define ST_STAMP_FLUSH() do { } while (0)
 #endif
 template <int NC, int DRIFT>
-__global__ __launch_bounds__(64 * ST_WAVES) __attribute__((amdgpu_waves_per_eu(NC <= 2 ? 3 : 2)))
+__global__ __launch_bounds__(64 * ST_WAVES) __attribute__((amdgpu_waves_per_eu(3)))
 void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     using DR = DriftT<DRIFT>;
     constexpr int D = DR::D, P = DR::P, TB = MAGI_TB;
@@ -116,7 +116,8 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     // block stream is still in the XCD's L2 (4 MB against 9 MB of blocks per XCD; tools/micro/readshape.hip: 5-15 % on the
     // load-only twin).  Chunk ck of the walk is physical chunk pc(ck); results are summed per PHYSICAL chunk so that they do
     // not depend on the direction.  (Only the one- and two-chain instantiations: four chains have no registers for it.)
-    constexpr bool ALT = NC <= 2;
+    static_assert(NC <= 2, "three or more chains per pass run k_stream_mc");
+    constexpr bool ALT = true;
     const int pc0 = (ALT && (parity & 1)) ? NCK - 1 : 0, pcs = (ALT && (parity & 1)) ? -1 : 1;
     double2 a0[8], a1[8];
     if ((threadIdx.x >> 6) >= NC) {
@@ -702,7 +703,8 @@ template <int NC, int DRIFT>
 int launch_stream_nd(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s) {
     const DevProblem& pb = h->pb;
     const dim3 grid(pb.n_tasks + (with_decisions ? NC : 0), (n_chains + NC - 1) / NC);      // + one decision workgroup per chain
-    hipLaunchKernelGGL((k_stream<NC, DRIFT>), grid, dim3(64 * ST_WAVES), 0, s, pb, h->ch, h->cfg, parity);
+    if (h->prof_e0) hipExtLaunchKernelGGL((k_stream<NC, DRIFT>), grid, dim3(64 * ST_WAVES), 0, s, h->prof_e0, h->prof_e1, 0, pb, h->ch, h->cfg, parity);
+    else hipLaunchKernelGGL((k_stream<NC, DRIFT>), grid, dim3(64 * ST_WAVES), 0, s, pb, h->ch, h->cfg, parity);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("stream launch: ") + hipGetErrorString(e));
     return MAGI_OK;
@@ -720,31 +722,34 @@ int launch_stream_nc(magi_handle* h, int n_chains, int parity, bool with_decisio
 
 int magi_leap_wgs(const DevProblem& pb) { return (pb.N + PT_POINTS - 1) / PT_POINTS; }
 
-// which streaming kernel serves >= 3 chains per GPU: the matrix-core kernel (default) or the VALU kernel in groups of four
-// (MAGI_STREAM_KERNEL=valu, for A/B measurements)
-static bool use_mc_kernel() {
-    static const bool v = [] { const char* e = getenv("MAGI_STREAM_KERNEL"); return !(e && std::string(e) == "valu"); }();
-    return v;
-}
-
 template <int DRIFT>
 int launch_stream_mc(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s) {
     const DevProblem& pb = h->pb;
     const int groups = (n_chains + MC - 1) / MC;
     const dim3 grid(pb.n_tasks + (with_decisions ? MC : 0), groups);
-    hipLaunchKernelGGL((k_stream_mc<DRIFT>), grid, dim3(256), 0, s, pb, h->ch, h->cfg, parity);
+    if (h->prof_e0) hipExtLaunchKernelGGL((k_stream_mc<DRIFT>), grid, dim3(256), 0, s, h->prof_e0, h->prof_e1, 0, pb, h->ch, h->cfg, parity);
+    else hipLaunchKernelGGL((k_stream_mc<DRIFT>), grid, dim3(256), 0, s, pb, h->ch, h->cfg, parity);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("stream (matrix-core) launch: ") + hipGetErrorString(e));
     return MAGI_OK;
 }
 
+// Which kernel family streams the operator blocks: one or two chains -> the VALU kernel k_stream<1 | 2>, three or more -> the
+// matrix-core kernel k_stream_mc.  The two sum in different orders, so a chain's rounding depends on the size of the batch it
+// runs in (1-2 against >= 3).  MAGI_STREAM_FAMILY=mc routes EVERY batch size through the matrix-core kernel: a chain's samples
+// are then bit-identical whatever shares the GPU with it (uneven shards, e.g. 5 chains on 2 GPUs = 3 + 2), at the price of the
+// slower kernel for one or two chains.  Read at every sampler initialisation (magi_ensure_chains).
+bool magi_stream_family_mc(int n_chains) {
+    const char* e = getenv("MAGI_STREAM_FAMILY");
+    return n_chains >= 3 || (e && std::string(e) == "mc");
+}
+
 int magi_launch_stream(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s) {
-    if (n_chains >= 3 && use_mc_kernel()) {
+    if (h->family_mc) {
 #define MAGI_CALL(DR) return launch_stream_mc<DR>(h, n_chains, parity, with_decisions, s)
         MAGI_DRIFT_DISPATCH(h->pb.drift, MAGI_CALL);
 #undef MAGI_CALL
     }
-    if (n_chains >= 3) return launch_stream_nc<4>(h, n_chains, parity, with_decisions, s);
     if (n_chains == 2) return launch_stream_nc<2>(h, n_chains, parity, with_decisions, s);
     return launch_stream_nc<1>(h, n_chains, parity, with_decisions, s);
 }
@@ -752,7 +757,8 @@ int magi_launch_stream(magi_handle* h, int n_chains, int parity, bool with_decis
 int magi_launch_point(magi_handle* h, int n_chains, int parity, hipStream_t s) {
     const DevProblem& pb = h->pb;
     const dim3 g(magi_leap_wgs(pb), n_chains), b(PT_THREADS);
-#define MAGI_CALL(DR) hipLaunchKernelGGL(k_point<DR>, g, b, 0, s, pb, h->ch, parity)
+#define MAGI_CALL(DR) do { if (h->prof_e0) hipExtLaunchKernelGGL(k_point<DR>, g, b, 0, s, h->prof_e0, h->prof_e1, 0, pb, h->ch, parity); \
+                           else hipLaunchKernelGGL(k_point<DR>, g, b, 0, s, pb, h->ch, parity); } while (0)
     MAGI_DRIFT_DISPATCH(pb.drift, MAGI_CALL);
 #undef MAGI_CALL
     hipError_t e = hipGetLastError();

@@ -102,7 +102,7 @@ struct GridPoint {     // component d of grid index i of one chain (one lane)
             *(vb + (size_t)(V_P + (lp.cur ^ 1)) * dimp + e) = pnext;
             const double xn = xd + lp.eps * pnext;
             *(vb + (size_t)(V_Q + (lp.cur ^ 1)) * dimp + e) = xn;
-            if (ch.n_chains >= 3) ch.xop[xop_off(pb, ch.n_chains, xop_buf, cc, d, i)] = xn;      // (three or more chains: the matrix-core stream of the NEXT slot reads this mirror)
+            if (ch.mc) ch.xop[xop_off(pb, ch.n_chains, xop_buf, cc, d, i)] = xn;      // (three or more chains: the matrix-core stream of the NEXT slot reads this mirror)
         }
     }
 };

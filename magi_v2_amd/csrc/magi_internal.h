@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdint>
@@ -140,7 +141,8 @@ struct GlobalCtl {
     int all_done;      // every chain idle: the mat-vec kernels and the tail return immediately
     int stop_k;        // chains pause once they have finished this many transitions
     int epoch;         // incremented by the host at every magi_sampler_run
-    int pad[3];
+    int slots;         // leapfrog slots issued in this run before every chain was idle (counted by chain 0's decision workgroup)
+    int pad[2];
 };
 
 // What the streaming kernel's epilogue must do for a chain in the next leapfrog slot; written by the
@@ -184,6 +186,7 @@ struct DevChains {
     double* par;          // [n_chains][PAR_COUNT] transformed parameters of the state in V_Q
     GlobalCtl* gctl;
     int n_chains;
+    int mc;               // the matrix-core streaming kernel serves this batch (three or more chains, or MAGI_STREAM_FAMILY=mc): keep xop up to date
     // outputs
     double* samples;      // [n_chains][num_results][dimp]
     double* d_step_size;  // diag arrays [n_chains][total]
@@ -746,7 +749,7 @@ struct magi_handle {
     size_t tiles_cap = 0, tasks_cap = 0;
     // work space of the matrix build and the packing, kept between calls (grow-only): a repeated build at N = 8192 otherwise spends
     // more host time in hipMalloc / hipFree of ~35 GB than the GPU spends on the build
-    enum { WS_KAP = 0, WS_P, WS_PP, WS_DINV, WS_PANEL, WS_TCS, WS_TM, WS_TKS, WS_TE, WS_COUNT };
+    enum { WS_KAP = 0, WS_P, WS_PP, WS_DINV, WS_PANEL, WS_TCS, WS_TM, WS_TKS, WS_TE, WS_APPLY, WS_COUNT };
     double* ws[WS_COUNT] = {};
     size_t ws_cap[WS_COUNT] = {};
 
@@ -756,6 +759,7 @@ struct magi_handle {
     DevChains ch{};
     SamplerCfgDev cfg{};
     bool sampler_ready = false;
+    bool family_mc = false;          // magi_stream_family_mc(n_chains) at the last magi_ensure_chains
     int num_results = 0;
     // graph of G leapfrog slots
     hipGraph_t graph = nullptr;
@@ -770,6 +774,12 @@ struct magi_handle {
     long long* d_chain_ids = nullptr;
     double* d_fin = nullptr;         // [cap_chains][8] finalize outputs
     size_t samples_cap = 0, diag_cap = 0;
+    // magi_sampler_profile: when set, the launchers of k_stream / k_point attach these events to the launch (hipExtLaunchKernel:
+    // they take the kernel's own begin / end time stamps, what rocprofv3's kernel trace reports)
+    hipEvent_t prof_e0 = nullptr, prof_e1 = nullptr;
+    long long last_slots = 0, last_graphs = 0;      // of the last magi_sampler_run
+    double* apply_pin = nullptr;     // pinned staging of magi_dense_apply (V | Y)
+    size_t apply_pin_cap = 0;
 };
 
 // work-space slot `k` with room for n doubles (grow-only; freed by magi_destroy); nullptr + error on failure
@@ -796,6 +806,7 @@ int magi_launch_stream(magi_handle* h, int n_chains, int parity, bool with_decis
 int magi_launch_point(magi_handle* h, int n_chains, int parity, hipStream_t s);                            // k_point: leapfrog epilogue per grid point
 int magi_launch_leap_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s);
 int magi_leap_wgs(const DevProblem& pb);
+bool magi_stream_family_mc(int n_chains);        // leap.hip
 int magi_build_profile_get(double* flops, double* ms, long* calls);           // build.hip
 int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const double* X, const double* mu, const double* mu_phi2,
                             const double* sd_phi2, const double* sig_loc, double nu, int iters, double lr, double jitter,

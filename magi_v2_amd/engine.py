@@ -63,6 +63,10 @@ _SYMBOLS = {
     "magi_sampler_get_diag": (C.c_int, [C.c_void_p, _dp, _dp, _ip, _ip, _ip, _ip, _ip, _dp, _dp, _dp]),
     "magi_sampler_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp]),
     "magi_sample": (C.c_int, [C.c_void_p, C.POINTER(SamplerCfg), C.c_int, _dp, _dp, _dp, C.c_uint64, _lp, _dp, _dp, _dp]),
+    "magi_sampler_get_checkpoint": (C.c_int, [C.c_void_p, _dp]),
+    "magi_sampler_set_checkpoint": (C.c_int, [C.c_void_p, _dp]),
+    "magi_sampler_run_stats": (C.c_int, [C.c_void_p, _lp, _lp]),
+    "magi_sampler_profile": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _lp]),
     "magi_time_gradient": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp]),
     "magi_gradient_bytes": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "magi_debug_par": (C.c_int, [C.c_void_p, C.c_int, _dp]),
@@ -334,6 +338,35 @@ class MagiEngine:
         ss, bc = np.empty(n), np.empty(n)
         self._check(self._lib.magi_sampler_get_state(self._h, _ptr(X), _ptr(sp), _ptr(tp), _ptr(ss), _ptr(bc)))
         return X, sp, tp, ss, bc
+
+    CKPT_SCALARS = 16
+
+    def sampler_checkpoint(self):
+        """Everything needed to resume the chains at the transition boundary they stand at (between two sampler_run calls):
+        dict(X, sig_pre, th_pre, scalars).  See include/magi_hip.h (magi_sampler_get_checkpoint)."""
+        X, sp, tp, _, _ = self.sampler_state()
+        sc = np.zeros((self.n_chains, self.CKPT_SCALARS))
+        self._check(self._lib.magi_sampler_get_checkpoint(self._h, _ptr(sc)))
+        return {"X": X, "sig_pre": sp, "th_pre": tp, "scalars": sc}
+
+    def sampler_resume(self, cfg: SamplerCfg, ckpt, seed: int, chain_ids: Optional[Sequence[int]] = None):
+        """sampler_init at the checkpointed states + the checkpoint's scalars: the next sampler_run continues the run."""
+        self.sampler_init(cfg, ckpt["X"], ckpt["sig_pre"], ckpt["th_pre"], seed, chain_ids)
+        sc = _f64(ckpt["scalars"], (self.n_chains, self.CKPT_SCALARS))
+        self._check(self._lib.magi_sampler_set_checkpoint(self._h, _ptr(sc)))
+
+    def sampler_run_stats(self):
+        """(leapfrog slots issued, graph launches) of the last sampler_run."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.magi_sampler_run_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def sampler_profile(self, n_slots=512):
+        """Mean in-sampler device time (us) per launch of the streaming kernel and of k_point over n_slots slots launched with
+        per-kernel HIP events; returns (stream_us, point_us, leapfrogs).  The sampler must be re-initialised afterwards."""
+        a, b, lf = C.c_double(0.0), C.c_double(0.0), C.c_int64(0)
+        self._check(self._lib.magi_sampler_profile(self._h, int(n_slots), C.byref(a), C.byref(b), C.byref(lf)))
+        return a.value, b.value, lf.value
 
     # -- instrumentation ------------------------------------------------------------------------
     def time_gradient(self, n_chains=1, reps=50):

@@ -23,18 +23,40 @@ def _hipcc() -> str:
     return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
-def _toolchain_digest() -> str:
-    """Sources + compiler version + extra flags: everything a cached library depends on besides the drift header."""
+def _source_digest() -> str:
+    """Sources + extra flags: what a cached library depends on besides the drift header and the compiler."""
     h = hashlib.sha256()
     for f in sorted(_build.sources() + glob.glob(os.path.join(_build.CSRC, "*.h")) + [os.path.join(_build.HERE, "..", "include", "magi_hip.h")]):
         with open(f, "rb") as fh:
             h.update(fh.read())
-    try:
-        h.update(subprocess.run([_hipcc(), "--version"], capture_output=True, check=False).stdout)
-    except OSError:
-        pass
     h.update(os.environ.get("MAGI_EXTRA_CFLAGS", "").encode())
     return h.hexdigest()[:12]
+
+
+def _compiler_version() -> str:
+    """``hipcc --version`` ("" when there is no compiler on this machine)."""
+    try:
+        return subprocess.run([_hipcc(), "--version"], capture_output=True, check=False).stdout.decode(errors="replace")
+    except OSError:
+        return ""
+
+
+def _cached_library_usable(d: str, lib: str) -> bool:
+    """A library built from these very sources for this very drift header exists: use it when it was built by the compiler found
+    here, when there is NO compiler here (a deployment box that received a prebuilt ``jit_cache/``), or when the caller vouches for
+    it with MAGI_JIT_CACHE_TRUST=1; otherwise it is rebuilt (same sources, another compiler)."""
+    if not os.path.exists(lib):
+        return False
+    if os.environ.get("MAGI_JIT_CACHE_TRUST") == "1":
+        return True
+    here = _compiler_version()
+    if not here:
+        return True
+    try:
+        with open(os.path.join(d, "compiler.txt")) as fh:
+            return fh.read() == here
+    except OSError:
+        return False
 
 
 def prune(keep_latest: int = 1) -> None:
@@ -57,16 +79,16 @@ def library_for(drift, verbose: bool = False) -> str:
     finished library is moved into place with one ``os.replace``."""
     if drift.header is None:
         raise ValueError("built-in drifts use the base library")
-    key = hashlib.sha256((drift.header + _toolchain_digest()).encode()).hexdigest()[:16]
+    key = hashlib.sha256((drift.header + _source_digest()).encode()).hexdigest()[:16]       # (the compiler is NOT in the key: see _cached_library_usable)
     d = os.path.join(CACHE, f"{drift.name}_{key}")
     lib = os.path.join(d, "libmagi_hip_user.so")
-    if os.path.exists(lib):
+    if _cached_library_usable(d, lib):
         return lib
     os.makedirs(d, exist_ok=True)
     with open(os.path.join(d, ".lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if os.path.exists(lib):                       # another process built it while we waited
+            if _cached_library_usable(d, lib):            # another process built it while we waited
                 return lib
             hdr = os.path.join(d, "user_drift.h")
             tmp_hdr = hdr + f".{os.getpid()}.tmp"
@@ -99,6 +121,9 @@ def library_for(drift, verbose: bool = False) -> str:
                         raise RuntimeError("hipcc failed for the traced drift:\n" + out.decode(errors="replace")[-4000:])
                 tmp = os.path.join(work, "libmagi_hip_user.so")
                 subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-Wl,-rpath,/opt/rocm/lib"])
+                with open(os.path.join(d, f"compiler.txt.{os.getpid()}.tmp"), "w") as fh:
+                    fh.write(_compiler_version())
+                os.replace(os.path.join(d, f"compiler.txt.{os.getpid()}.tmp"), os.path.join(d, "compiler.txt"))
                 os.replace(tmp, lib)
             finally:
                 shutil.rmtree(work, ignore_errors=True)

@@ -227,6 +227,42 @@ def matern_blocks(I: np.ndarray, phi1: float, phi2: float, v: float = 2.01):
     return Kappa, p_Kappa, Kappa_pp
 
 
+def matern_block_columns(I: np.ndarray, cols, phi1: float, phi2: float, v: float = 2.01):
+    """Columns ``cols`` of Kappa, p_Kappa, Kappa_pp ([N, len(cols)] each): the expressions of ``matern_blocks``
+    (magi_v2.py:781-815) evaluated on those columns only -- the truth side of the N = 8192 build test, where the full
+    N x N blocks (3 x 537 MB, three AMOS sweeps) are out of a test's reach."""
+    I = np.asarray(I, dtype=np.float64).reshape(-1)
+    cols = np.asarray(cols, dtype=np.int64)
+    s = np.repeat(I[:, None], len(cols), axis=1)
+    t = np.repeat(I[cols][None, :], len(I), axis=0)
+    diag = (np.arange(len(I))[:, None] == cols[None, :])
+    l = np.abs(s - t)
+    u = np.sqrt(2 * v) * l / phi2
+    u[diag] = np.nan
+    with np.errstate(invalid="ignore", divide="ignore"):
+        Bv0, Bv1, Bv2 = kvp(v=v, z=u, n=0), kvp(v=v, z=u, n=1), kvp(v=v, z=u, n=2)
+        Kappa = (phi1 / gamma(v)) * (2 ** (1 - (v / 2))) * ((np.sqrt(v) / phi2) ** v)
+        Kappa = Kappa * Bv0
+        Kappa *= (l ** v)
+        Kappa[diag] = phi1
+        p_Kappa = (2 ** (1 - (v / 2)))
+        p_Kappa = p_Kappa * phi1 * ((u / np.sqrt(2)) ** v)
+        p_Kappa *= ((u * phi2 * Bv1) + (v * phi2 * Bv0))
+        p_Kappa /= (phi2 * (s - t) * gamma(v))
+        p_Kappa[diag] = 0.0
+        Kappa_pp = 2 * np.sqrt(2) * (v ** 1.5) * phi2 * l * Bv1
+        Kappa_pp += (((v ** 2) * (phi2 ** 2)) - (v * (phi2 ** 2))) * Bv0
+        Kappa_pp += ((2 * v * (s ** 2)) - (4 * v * s * t) + (2 * v * (t ** 2))) * Bv2
+        Kappa_pp *= (-1.0 * (2 ** (1 - (v / 2))) * phi1 * ((u / np.sqrt(2)) ** v))
+        Kappa_pp /= ((phi2 ** 2) * (l ** 2) * gamma(v))
+        Kappa_pp[diag] = v * phi1 / ((phi2 ** 2) * (v - 1))
+    # scipy's kvp underflows to exact zeros (and 0 * inf = NaN in the products above) beyond u ~ 700: those entries are zero
+    far = u > 600.0
+    for A in (Kappa, p_Kappa, Kappa_pp):
+        A[far & ~np.isfinite(A)] = 0.0
+    return Kappa, p_Kappa, Kappa_pp
+
+
 def build_matrices(I: np.ndarray, phi1: float, phi2: float, v: float = 2.01):
     """``_build_matrices`` (magi_v2.py:774-823): returns (C_d, m_d, K_d)."""
     Kappa, p_Kappa, Kappa_pp = matern_blocks(I, phi1, phi2, v)

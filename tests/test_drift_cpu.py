@@ -138,3 +138,24 @@ def test_jit_library_for_is_safe_under_concurrent_callers(tmp_path, monkeypatch)
     assert os.path.exists(lib) and os.path.getsize(lib) > 100000
     left = [f for f in os.listdir(os.path.dirname(lib)) if f.startswith("build_") or f.endswith(".tmp")]
     assert left == [], left
+
+
+def test_prebuilt_jit_cache_is_used_without_a_compiler_and_rebuilt_for_another_one(monkeypatch):
+    """The cache key of a drift-specialised library is (drift header, library sources, extra flags) -- NOT the compiler: a box
+    that receives a prebuilt jit_cache/ and has no hipcc uses it as is, MAGI_JIT_CACHE_TRUST=1 vouches for it across compiler
+    versions, and only a box with a DIFFERENT compiler rebuilds (compiler.txt beside the library records who built it)."""
+    from magi_v2_amd import drift, jit
+    from magi_v2_amd.drift_examples import EXAMPLES
+    f, D, P = EXAMPLES["lotka_volterra"]
+    d = drift.resolve(f, D, P)
+    lib = jit.library_for(d)                                # built (or found) by this container's compiler
+    folder = os.path.dirname(lib)
+    assert open(os.path.join(folder, "compiler.txt")).read() == jit._compiler_version() != ""
+    stamp = os.path.getmtime(lib)
+    monkeypatch.setenv("HIPCC", "/nonexistent/hipcc")       # no compiler on this "box": the prebuilt library is used
+    assert jit._compiler_version() == "" and jit.library_for(d) == lib and os.path.getmtime(lib) == stamp
+    monkeypatch.delenv("HIPCC")
+    monkeypatch.setattr(jit, "_compiler_version", lambda: "some other hipcc 9.9")
+    assert not jit._cached_library_usable(folder, lib)      # another compiler: rebuild ...
+    monkeypatch.setenv("MAGI_JIT_CACHE_TRUST", "1")
+    assert jit._cached_library_usable(folder, lib)          # ... unless the caller vouches for the cache

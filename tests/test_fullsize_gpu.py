@@ -5,7 +5,20 @@ cannot run there in seconds:
     log posterior along random directions, (iii) C^-1 Kappa = I on random columns.
   * config 4 (alpha sweep): the ten thinned datasets x chains run end to end through the drop-in API.
   * config 3: chains are independent of how they are batched (ids keyed Philox), at N = 256 with 16 chains and at the
-    config's own size (N = 1024, 8 chains per GPU) with an oracle draw-for-draw check on the GPU-built matrices."""
+    config's own size (N = 1024, 8 chains per GPU) with an oracle draw-for-draw check on the GPU-built matrices.
+  * config 5 (N = 8192): the build's OUTPUTS against Matern columns evaluated by the oracle (never downloads a matrix).
+
+Which test pins which GEMM class of csrc/build.hip (k_gemm_f64<CLS>; the XCD-aware super-block tile order switches on by itself
+only above N = 4096, `MAGI_GEMM_REMAP_MIN=1` forces it on every launch):
+  <2> potrf panels, <3> potrf rank-k updates, <4> trtri, <5> T^T T, <6> W^T / m / K_d products
+      -- plain tile order:  test_full_size_inverse_properties[1024 / 2048] (dense host truth: C^-1 Kappa = I, m Kappa = p_Kappa,
+         K^-1 K_ref = I), tests/test_build_gpu.py (mpmath / reference golden at small N);
+      -- super-block order: test_remapped_tile_order_is_bit_identical_n2048 (every output equal BIT FOR BIT to the plain-order
+         build at a size where the dense host truth above applies), test_full_size_inverse_properties[2048-remap-*] (the same
+         host truth with the order forced and 2 / 8 panels per block column), test_config5_build_outputs_against_matern_columns
+         (N = 8192, the order as it runs in production, truth = oracle Matern columns);
+  <7> single-phase operators E = Ks M, H = M^T E + Cs: the fused vs three-phase log posterior at N = 1024 .. 8192
+      (test_full_size_logpost_consistency_and_gradient) and bit-identity of the fused log posterior under the forced order."""
 import os
 
 import numpy as np
@@ -71,16 +84,38 @@ def test_config5_sampler_runs_at_n8192():
     eng.close()
 
 
-@pytest.mark.parametrize("N", [1024, 2048])
-def test_full_size_inverse_properties(N):
+class _env:
+    """Environment switches of csrc/build.hip for the duration of a block (read by the library at every launch)."""
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items() if v is not None}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("N,remap,panels", [(1024, None, None), (2048, None, None), (2048, 1, 2), (2048, 1, 8)],
+                         ids=["1024", "2048", "2048-remap-2panels", "2048-remap-8panels"])
+def test_full_size_inverse_properties(N, remap, panels):
     """C^-1 Kappa = I, m Kappa = p_Kappa and K^-1 K_ref = I on random columns at BASELINE sizes; K_ref = Kappa_pp +
     p_Kappa Kappa^-1 p_Kappa is formed on the host from the GPU's Matern blocks (pinned against mpmath at small N).
-    K^-1 is the worst-conditioned product of the build: Schur complement, second Cholesky, second inverse."""
+    K^-1 is the worst-conditioned product of the build: Schur complement, second Cholesky, second inverse.
+    remap / panels: the XCD-aware super-block tile order forced on every GEMM launch (it switches on by itself only above
+    N = 4096) and 2 / 8 panels per potrf block column instead of 4 -- the code paths of the N = 8192 build at a size where
+    the dense host truth is affordable."""
     from magi_v2_amd.engine import MagiEngine
     EPS = np.finfo(float).eps
     I = np.arange(N) * 0.025
     eng = MagiEngine(0)
-    C_inv, m, K_inv = eng.build_matrices(I, [0.05], [0.1], 2.01)
+    with _env(MAGI_GEMM_REMAP_MIN=remap, MAGI_POTRF_PANELS=panels):
+        C_inv, m, K_inv = eng.build_matrices(I, [0.05], [0.1], 2.01)
     Kap, pK, Kpp = eng.matern_blocks(I, 0.05, 0.1, 2.01)
     cols = np.random.default_rng(0).integers(0, N, 16)
     cond = np.linalg.cond(Kap)
@@ -96,6 +131,83 @@ def test_full_size_inverse_properties(N):
     R[cols, np.arange(16)] -= 1.0
     assert np.abs(R).max() < 200 * cond * EPS * condK ** 0.5, (np.abs(R).max(), cond, condK)
     assert np.abs(K_inv[0] - K_inv[0].T).max() == 0.0
+    eng.close()
+
+
+def test_remapped_tile_order_is_bit_identical_n2048():
+    """The super-block tile order of k_gemm_f64 (csrc/build.hip: XCD x takes 8 x 8 super-blocks, rotated; lower-only launches
+    enumerate the lower super-blocks) only changes WHICH workgroup computes a tile, never the tile's arithmetic: with the order
+    forced (MAGI_GEMM_REMAP_MIN=1) every output of the build -- C^-1, m, K^-1 of two components with different hyper-parameters,
+    and the single-phase operators through the fused log posterior -- equals the plain-order build bit for bit.  A dropped,
+    duplicated or mis-placed tile in any GEMM class shows up here; the plain-order build itself is held to dense host truth
+    by test_full_size_inverse_properties[2048]."""
+    from magi_v2_amd.engine import MagiEngine
+    N = 2048
+    I, X_obs, truth, th = host.synthetic_seir(N, seed=0)
+    Xi = host.linear_interpolate(X_obs)
+    hp = host.hparams_initial(Xi)
+    N_ds, beta, idx, y = host.observation_bookkeeping(X_obs, X_obs)
+    Xhat = host.cubic_smoother(I, Xi)
+    LB = host.sigma_sqs_lower_bound(Xhat)
+    sp, tp = host.softplus_inverse_inits(hp["sigma_sqs"], th, LB)
+    X = Xhat + 0.01 * np.random.default_rng(5).standard_normal(Xhat.shape)
+
+    def build(remap):
+        eng = MagiEngine(0)
+        with _env(MAGI_GEMM_REMAP_MIN=remap):
+            mats = eng.build_matrices(I, hp["phi1s"], hp["phi2s"], 2.01)
+            eng.set_problem(Xi.mean(axis=0), N_ds.astype(np.float64), idx, y, beta, LB, "seir4")
+        out = mats + tuple(eng.logpost_grad(X, sp, tp, 0.8, fused=True))
+        eng.close()
+        return out
+
+    plain, forced = build(None), build(1)
+    for a, b, what in zip(plain, forced, ("C_inv", "m", "K_inv", "logp", "gX", "gsig", "gth")):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b), err_msg=what)
+    assert np.isfinite(plain[3]) and np.abs(plain[0]).max() > 0
+
+
+def test_config5_build_outputs_against_matern_columns():
+    """BASELINE config 5's build (N = 8192; magi_v2.py:818-820, 126-128) checked on its OUTPUTS without downloading a matrix:
+    16 random columns of Kappa, p_Kappa, Kappa_pp from the oracle's restatement of magi_v2.py:781-815 on those columns, and
+    the device-resident C^-1, m, K^-1 applied to them (magi_dense_apply):
+        C^-1 Kappa[:, c] = e_c,     m Kappa[:, c] = p_Kappa[:, c],     K^-1 K_ref[:, c] = e_c
+    with K_ref[:, c] = Kappa_pp[:, c] + m p_Kappa[:, c]  (K = Kappa_pp - p_Kappa Kappa^-1 Kappa_p, Kappa_p = -p_Kappa, :805, :820;
+    m was checked the line before).  At this size every large product runs in the super-block tile order.  Tolerances as in
+    test_full_size_inverse_properties; the condition numbers are those of the same grid spacing at N = 1024 (they do not grow
+    with N at fixed spacing: SURVEY section 7)."""
+    from magi_v2_amd.engine import MagiEngine
+    from oracle import magi_oracle as orc
+    EPS = np.finfo(float).eps
+    N, phi1, phi2 = 8192, 0.05, 0.1
+    I = np.arange(N) * 0.025
+    Ks, pKs, Kpps = orc.matern_blocks(I[:1024], phi1, phi2)
+    cond = np.linalg.cond(Ks)
+    Kref_s = Kpps + np.linalg.solve(Ks, pKs.T).T @ pKs
+    condK = np.linalg.cond(0.5 * (Kref_s + Kref_s.T))
+    eng = MagiEngine(0)
+    eng.build_matrices(I, [phi1], [phi2], 2.01, want_host=False)
+    cols = np.sort(np.random.default_rng(8192).choice(N, 16, replace=False))
+    cols[0], cols[-1] = 0, N - 1                                   # the ragged ends of the tile grid included
+    Kap, pK, Kpp = orc.matern_block_columns(I, cols, phi1, phi2)
+
+    def apply(which, V):                                           # [N, 16] -> [N, 16], eight columns per call
+        return np.concatenate([eng.dense_apply(which, V[None, :, k:k + 8])[0] for k in (0, 8)], axis=1)
+
+    E = np.zeros((N, 16))
+    E[cols, np.arange(16)] = 1.0
+    R = apply("C_inv", Kap) - E
+    assert np.abs(R).max() < 100 * cond * EPS, ("C^-1 Kappa", np.abs(R).max(), cond)
+    mK = apply("m", Kap)
+    assert np.abs(mK - pK).max() < 100 * cond * EPS * np.abs(pK).max(), ("m Kappa", np.abs(mK - pK).max())
+    K_ref = Kpp + apply("m", pK)
+    R = apply("K_inv", K_ref) - E
+    assert np.abs(R).max() < 200 * cond * EPS * condK ** 0.5, ("K^-1 K", np.abs(R).max(), cond, condK)
+    # transposes: C^-1 and K^-1 are symmetric by construction, so A^T v must reproduce A v to rounding of the summation order
+    v = np.random.default_rng(1).standard_normal((1, N))
+    for which in ("C_inv", "K_inv"):
+        a, b = eng.dense_apply(which, v), eng.dense_apply(which, v, transpose=True)
+        assert np.abs(a - b).max() <= 1e-9 * np.abs(a).max(), which
     eng.close()
 
 
@@ -173,8 +285,10 @@ def test_config3_at_size_n1024_eight_chains_per_gpu():
     assert ids == list(range(8, 16))
     # (from TFP's initial step 0.1 every early proposal on this grid diverges at its first leaf and the chains never move:
     #  start at the step size the adaptation settles at, so that the transitions build trees and accept states)
-    burnin, results, seed, step0 = 2, 1, 77, 1e-3
-    cfg = eng.default_cfg(num_results=results, num_burnin_steps=burnin, stale_cache=0, step_size=step0)
+    # 8 transitions (6 burn-in, of which 4 adapt the step size, + 2 kept), trees capped at depth 8 so that the oracle's share
+    # (one numpy gradient per leapfrog at N = 1024) stays within a minute
+    burnin, results, seed, step0, depth = 6, 2, 77, 1e-3, 8
+    cfg = eng.default_cfg(num_results=results, num_burnin_steps=burnin, stale_cache=0, step_size=step0, max_tree_depth=depth)
     rep = lambda v, n: np.repeat(np.asarray(v)[None], n, axis=0)
 
     def run(chain_ids):
@@ -185,7 +299,7 @@ def test_config3_at_size_n1024_eight_chains_per_gpu():
 
     (X8, s8, t8), d8, lf8 = run(ids)
     assert lf8 == d8.leapfrogs_taken.sum() and np.isfinite(X8).all()
-    assert d8.leapfrogs_taken.max() >= 15 and d8.is_accepted.sum() >= 8 and not np.array_equal(t8[0], t8[1])      # trees grow, states move, chains differ
+    assert d8.leapfrogs_taken.max() >= 31 and d8.is_accepted.sum() >= 16 and not np.array_equal(t8[0], t8[1])     # trees grow, states move, chains differ
     for part in (ids[:4], ids[4:], ids[5:8], [ids[2]], [ids[7]]):
         (Xp, sp_, tp_), dp, _ = run(part)
         sel = [ids.index(c) for c in part]
@@ -203,7 +317,7 @@ def test_config3_at_size_n1024_eight_chains_per_gpu():
                      beta=float(beta), LB=LB, drift="seir4", P=P)
     trace = []
     oX, osp, otp, info, _ = orc.sample_chain(pr, Xhat, hp["sigma_sqs"], np.ones(P), results, burnin, seed=seed, chain=ids[0],
-                                             step_size=step0, stale_cache=False, trace=trace)
+                                             step_size=step0, stale_cache=False, trace=trace, max_tree_depth=depth)
     np.testing.assert_array_equal(d8.tree_depth[0], [r.depth for _, r, _ in trace])
     np.testing.assert_array_equal(d8.leapfrogs_taken[0], [r.leapfrogs for _, r, _ in trace])
     np.testing.assert_array_equal(d8.is_accepted[0], [int(r.is_accepted) for _, r, _ in trace])

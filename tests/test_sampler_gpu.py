@@ -188,3 +188,108 @@ def test_fixed_length_hmc_batched_matches_oracle():
         np.testing.assert_allclose(d.step_size[i], [s for _, _, s in trace], rtol=1e-8)
         np.testing.assert_allclose(tp[i], otp, rtol=1e-7, atol=1e-9)
         np.testing.assert_allclose(Xs[i], oX, rtol=0, atol=1e-8 * np.abs(oX).max())
+
+
+def test_two_chains_match_oracle_draw_for_draw():
+    """Exactly two chains per GPU run the two-chain instantiation of the VALU streaming kernel (k_stream<2, *>): both chains
+    against the oracle draw for draw, and equal to the same ids run one at a time (k_stream<1, *>) to rounding."""
+    (Xs, sp, tp, diag, lf), oracle = _run_both("seir4_N81", None, 6, 3, seed=321, chain_ids=(4, 9), stale=0)
+    for i in range(2):
+        (oX, osp, otp, info, da), trace = oracle[i]
+        np.testing.assert_array_equal(diag.tree_depth[i], [r.depth for _, r, _ in trace])
+        np.testing.assert_array_equal(diag.leapfrogs_taken[i], [r.leapfrogs for _, r, _ in trace])
+        np.testing.assert_array_equal(diag.is_accepted[i], [int(r.is_accepted) for _, r, _ in trace])
+        np.testing.assert_allclose(diag.step_size[i], [s for _, _, s in trace], rtol=1e-9)
+        np.testing.assert_allclose(Xs[i], oX, rtol=0, atol=1e-8 * np.abs(oX).max())
+        np.testing.assert_allclose(tp[i], otp, rtol=1e-7, atol=1e-9)
+    assert lf == diag.leapfrogs_taken.sum() and not np.allclose(tp[0], tp[1])
+
+
+def test_one_kernel_family_makes_a_chain_independent_of_its_batch_size(monkeypatch):
+    """MAGI_STREAM_FAMILY=mc routes every batch size through the matrix-core streaming kernel: chain 7 run alone, in a pair
+    and inside a batch of five gives the same samples BIT FOR BIT (by default one or two chains run the VALU kernel, which sums
+    in another order: same chain to rounding only -- what an uneven shard such as 5 chains on 2 GPUs = 3 + 2 would meet)."""
+    g = load_g4("sirw_N41")
+    pr = problem_from_g4(g, None)
+    X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], np.ones(pr.P), pr.LB)
+
+    def run(ids):
+        eng = engine_for(pr, None)
+        cfg = eng.default_cfg(num_results=4, num_burnin_steps=6)
+        rep = lambda v: np.repeat(np.asarray(v)[None], len(ids), axis=0)
+        eng.sampler_init(cfg, rep(X0), rep(s0), rep(t0), seed=31, chain_ids=ids)
+        eng.sampler_run(10)
+        out = eng.sampler_samples(), eng.sampler_diag().leapfrogs_taken
+        eng.close()
+        return out
+
+    (_, _, t_def), _ = run([7])                        # default family for one chain (VALU kernel)
+    monkeypatch.setenv("MAGI_STREAM_FAMILY", "mc")
+    (X1, s1, t1), lf1 = run([7])
+    (X2, s2, t2), lf2 = run([3, 7])
+    (X5, s5, t5), lf5 = run([0, 7, 1, 2, 3])
+    np.testing.assert_array_equal(t1[0], t2[1]); np.testing.assert_array_equal(X1[0], X2[1])
+    np.testing.assert_array_equal(t1[0], t5[1]); np.testing.assert_array_equal(X1[0], X5[1])
+    np.testing.assert_array_equal(lf1[0], lf5[1])
+    np.testing.assert_allclose(t_def[0], t1[0], rtol=1e-6)          # the two families agree to rounding
+
+
+def test_slot_budget_exit_reports_the_stuck_chain_and_the_handle_stays_usable(monkeypatch):
+    """The pump of magi_sampler_run is bounded: a run that outlives its slot budget returns MAGI_E_STATE naming the chain's
+    k / phase / depth (csrc/capi.hip).  Forced here with a one-graph budget (64 slots) on transitions that need more; the
+    handle is then re-initialised and runs the same chain to completion."""
+    from magi_v2_amd.engine import MagiHipError
+    g = load_g4("seir4_N81")
+    pr = problem_from_g4(g, None)
+    eng = engine_for(pr, None)
+    X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], np.ones(pr.P), pr.LB)
+    cfg = eng.default_cfg(num_results=2, num_burnin_steps=6, step_size=1e-3)        # (a small first step: deep trees, > 64 slots)
+    eng.sampler_init(cfg, X0, s0, t0, seed=1234)
+    monkeypatch.setenv("MAGI_SLOT_BUDGET_GRAPHS", "1")
+    with pytest.raises(MagiHipError) as ei:
+        eng.sampler_run(8)
+    assert ei.value.code == -5 and "slot budget" in str(ei.value) and "chain 0: k=" in str(ei.value)
+    with pytest.raises(MagiHipError):                  # the interrupted sampler refuses to go on
+        eng.sampler_run(1)
+    monkeypatch.delenv("MAGI_SLOT_BUDGET_GRAPHS")
+    eng.sampler_init(cfg, X0, s0, t0, seed=1234)
+    lf, _ = eng.sampler_run(8)
+    slots, graphs = eng.sampler_run_stats()
+    d = eng.sampler_diag()
+    assert lf == d.leapfrogs_taken.sum() and lf > 64 and slots >= lf and graphs * 64 >= slots
+    _, _, otp, _, _ = orc.sample_chain(pr, g["Xhat_init"], g["sigma_sqs_init"], np.ones(pr.P), 2, 6, seed=1234, step_size=1e-3)
+    np.testing.assert_allclose(eng.sampler_samples()[2][0], otp, rtol=1e-7, atol=1e-9)
+    eng.close()
+
+
+@pytest.mark.parametrize("n_chains", [1, 4])
+def test_checkpoint_resume_in_a_new_handle_continues_the_run_bit_for_bit(n_chains):
+    """magi_sampler_get_checkpoint / set_checkpoint: 7 transitions, checkpoint, a NEW handle resumed from the checkpoint runs
+    the remaining 5 -- its samples and diagnostics of those steps equal the uninterrupted 12-step run bit for bit (one chain:
+    VALU kernel; four: matrix-core kernel).  The reference has no resume (a run is all-or-nothing, magi_v2.py:386-425)."""
+    g = load_g4("sirw_N41")
+    pr = problem_from_g4(g, None)
+    X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], np.ones(pr.P), pr.LB)
+    rep = lambda v: np.repeat(np.asarray(v)[None], n_chains, axis=0)
+    ids = list(range(10, 10 + n_chains))
+    burnin, results = 8, 4
+    eng = engine_for(pr, None)
+    cfg = eng.default_cfg(num_results=results, num_burnin_steps=burnin)
+    eng.sampler_init(cfg, rep(X0), rep(s0), rep(t0), seed=17, chain_ids=ids)
+    eng.sampler_run(burnin + results)
+    full, dfull = eng.sampler_samples(), eng.sampler_diag()
+    eng.sampler_init(cfg, rep(X0), rep(s0), rep(t0), seed=17, chain_ids=ids)
+    eng.sampler_run(7)
+    ck = eng.sampler_checkpoint()
+    assert list(ck["scalars"][:, 0]) == [7.0] * n_chains
+    eng.close()
+    eng2 = engine_for(pr, None)
+    eng2.sampler_resume(cfg, ck, seed=17, chain_ids=ids)
+    assert list(eng2.sampler_steps_done()) == [7] * n_chains
+    eng2.sampler_run(5)
+    part, dpart = eng2.sampler_samples(), eng2.sampler_diag()
+    eng2.close()
+    for a, b in zip(full, part):                       # steps 8..11 are the four kept samples
+        np.testing.assert_array_equal(a, b)
+    for f in ("leapfrogs_taken", "tree_depth", "step_size", "target_log_prob", "is_accepted"):
+        np.testing.assert_array_equal(getattr(dfull, f)[:, 7:], getattr(dpart, f)[:, 7:])
