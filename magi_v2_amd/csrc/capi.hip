@@ -44,7 +44,7 @@ void free_matrices(magi_handle* h) {
 
 void free_chains(magi_handle* h) {
     DevChains& c = h->ch;
-    free_dev(c.vec); free_dev(c.ctl); free_dev(c.par); free_dev(c.plan); free_dev(c.part); free_dev(c.tpart); free_dev(c.xop); free_dev(c.gctl); free_dev(c.samples);
+    free_dev(c.vec); free_dev(c.ctl); free_dev(c.par); free_dev(c.plan); free_dev(c.part); free_dev(c.tpart); free_dev(c.xop); free_dev(c.vop); free_dev(c.gctl); free_dev(c.samples);
     free_dev(c.d_step_size); free_dev(c.d_lar); free_dev(c.d_target); free_dev(c.d_energy); free_dev(c.d_beta);
     free_dev(c.d_leapfrogs); free_dev(c.d_depth); free_dev(c.d_flags);
     free_dev(h->d_chain_ids); free_dev(h->d_fin);
@@ -139,12 +139,16 @@ int magi_ensure_chains(magi_handle* h, int n) {
         h->ch.n_wg = magi_leap_wgs(h->pb);
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.part, sizeof(double) * PART_K * h->ch.n_wg * n));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.part, 0, sizeof(double) * PART_K * h->ch.n_wg * n));
-        const size_t tpn = (size_t)n * 4 * h->pb.D * h->pb.nb * h->pb.Np;
+        const bool sep = magi_drift_separable(h->pb.drift);
+        const size_t tpn = sep ? magi_sep_tpart_elems(h->pb, n) : (size_t)n * 4 * h->pb.D * h->pb.nb * h->pb.Np;
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.tpart, sizeof(double) * tpn));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.tpart, 0, sizeof(double) * tpn));     // slots outside the block band stay zero
         const size_t opn = (size_t)2 * ((n + 15) / 16) * h->pb.D * h->pb.Np * 16;
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.xop, sizeof(double) * opn));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.xop, 0, sizeof(double) * opn));
+        h->vop_elems = sep ? magi_sep_vop_elems(h->pb, n) : 16;
+        MAGI_HIP_CHECK(h, hipMalloc(&h->ch.vop, sizeof(double) * h->vop_elems));
+        MAGI_HIP_CHECK(h, hipMemset(h->ch.vop, 0, sizeof(double) * h->vop_elems));
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.gctl, sizeof(GlobalCtl)));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.gctl, 0, sizeof(GlobalCtl)));
         MAGI_HIP_CHECK(h, hipMalloc(&h->d_chain_ids, sizeof(long long) * n));
@@ -153,6 +157,8 @@ int magi_ensure_chains(magi_handle* h, int n) {
     }
     const bool fam = magi_stream_family_mc(n);
     if (h->n_chains != n || fam != h->family_mc) drop_graph(h);
+    if (h->n_chains != n && h->ch.vop)       // the mirror's layout depends on the chain count: entries the new layout never writes must read zero
+        MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.vop, 0, sizeof(double) * h->vop_elems, h->stream));
     h->n_chains = n;
     h->ch.n_chains = n;
     h->family_mc = fam;

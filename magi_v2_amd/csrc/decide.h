@@ -115,7 +115,7 @@ __device__ __forceinline__ LeafPlan make_leaf_plan(const ChainCtl& c, unsigned l
 // (they complete slot parity ^ 1 ... i.e. the slot the point phase executed last, and write plan[parity]).
 template <int DRIFT>
 __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChains& ch, const SamplerCfgDev& cfg, int chain, int parity, int all_done,
-                                             double* sh /* 25*16 */, double* shs /* 24 */, ChainCtl* s_ctl, int* s_g, double* s_par /* PAR_COUNT */, double* s_ops /* OPS_COUNT * OPS_W */, double* s_cst /* 2 * MAGI_MAX_D */) {
+                                             double* sh /* 25*16 */, double* shs /* 24 */, ChainCtl* s_ctl, int* s_g, double* s_par /* PAR_COUNT */, double* s_ops /* OPS_COUNT * OPS_W */, double* s_cst /* 3 * MAGI_MAX_D: N_ds, LB, mu */) {
     const int tid = threadIdx.x;
     MAGI_STAMP(ch.par, 8);
     // ONE round of loads with no dependence on anything: control state, the previous plan, the state's parameter block
@@ -145,7 +145,7 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
     if (tid >= 64 && tid < 64 + PAR_COUNT) s_par[tid - 64] = par_v;
     if (tid == PT_THREADS - 3) {
 #pragma unroll
-        for (int k = 0; k < MAGI_MAX_D; ++k) { s_cst[k] = pb.N_ds[k]; s_cst[MAGI_MAX_D + k] = pb.LB[k]; }      // (static indices)
+        for (int k = 0; k < MAGI_MAX_D; ++k) { s_cst[k] = pb.N_ds[k]; s_cst[MAGI_MAX_D + k] = pb.LB[k]; s_cst[2 * MAGI_MAX_D + k] = pb.mu[k]; }      // (static indices)
     }
     reduce_prefetch_ops_store<OPS_PER>(ops_v, s_ops);
     MAGI_STAMP(ch.par, 2);
@@ -489,9 +489,36 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
                     pw[e] = ph;
                     const double qn = q0[u] + eps * ph;
                     qw[e] = qn;
-                    if (ch.mc && e < pb.ND) { const int dd = e / pb.N; ch.xop[xop_off(pb, ch.n_chains, parity ^ 1, chain, dd, e - dd * pb.N)] = qn; }   // (read by the next slot's stream)
+                    if (!DriftT<DRIFT>::SEP && ch.mc && e < pb.ND) { const int dd = e / pb.N; ch.xop[xop_off(pb, ch.n_chains, parity ^ 1, chain, dd, e - dd * pb.N)] = qn; }   // (read by the next slot's stream)
                     v.rhosub[e] = 0.0;
                     if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par, true, s_cst + MAGI_MAX_D);
+                }
+            }
+        }
+        if constexpr (DriftT<DRIFT>::SEP) {
+            // operand mirror of the new state for the next slot's stream (k_stream_sep): xc and the basis values phi_{d,k} need ALL
+            // components of a grid point, so the positions are formed again per point (same expressions, same rounding as above)
+            using DR = DriftT<DRIFT>;
+            constexpr int DD = DR::D, NBM = DR::NBMAX;
+            const int cw = xop_width(ch.n_chains), groups = (ch.n_chains + 15) >> 4, cl = chain & 15;
+            const int planes = 1 + (NBM * cw + 15) / 16;
+            for (int i = tid; i < pb.N; i += (int)blockDim.x) {
+                double xq[DD], ph[DD][NBM];
+#pragma unroll
+                for (int dd = 0; dd < DD; ++dd) {
+                    const int e = dd * pb.N + i;
+                    const double phh = pe[e] + hs * ge[e];
+                    xq[dd] = qe[e] + eps * phh;
+                }
+                DR::basis(xq, ph);
+#pragma unroll
+                for (int dd = 0; dd < DD; ++dd) {
+                    double* m0 = ch.vop + vop_off(DD, planes, pb.Np, groups, parity ^ 1, chain >> 4, dd, 0, i);
+                    m0[cl] = xq[dd] - s_cst[2 * MAGI_MAX_D + dd];
+#pragma unroll
+                    for (int k = 0; k < NBM; ++k)
+                        if (k < DR::nbasis(dd))
+                            m0[(size_t)(cw == 8 ? 1 + (k >> 1) : 1 + k) * pb.Np * 16 + (cw == 8 ? (k & 1) * 8 + cl : cl)] = ph[dd][k];
                 }
             }
         }

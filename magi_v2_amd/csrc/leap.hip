@@ -93,7 +93,7 @@ void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
         __shared__ int s_g[2];
         __shared__ double s_par[PAR_COUNT];
         __shared__ double s_ops[OPS_COUNT * OPS_W];
-        __shared__ double s_cst[2 * MAGI_MAX_D];
+        __shared__ double s_cst[3 * MAGI_MAX_D];
         const int chain = c0 + (int)blockIdx.x;
         if (chain < ch.n_chains) decide_block<DRIFT>(pb, ch, cfg, chain, parity, all_done, dsh, dshs, &s_ctl, s_g, s_par, s_ops, s_cst);
         return;
@@ -358,10 +358,10 @@ void k_stream_mc(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
         double* dshs = dsh + 25 * 16;                         // 24
         double* s_par = dshs + 24;                            // PAR_COUNT
         double* s_ops = s_par + PAR_COUNT;                    // OPS_COUNT * OPS_W
-        double* s_cst = s_ops + OPS_COUNT * OPS_W;            // 2 * MAGI_MAX_D
-        int* s_g = reinterpret_cast<int*>(s_cst + 2 * MAGI_MAX_D);
-        ChainCtl* s_ctl = reinterpret_cast<ChainCtl*>(s_cst + 2 * MAGI_MAX_D + 2);
-        static_assert(25 * 16 + 24 + PAR_COUNT + OPS_COUNT * OPS_W + 2 * MAGI_MAX_D + 2 + (sizeof(ChainCtl) + 7) / 8 <= MC_SM_DOUBLES, "decision scratch");
+        double* s_cst = s_ops + OPS_COUNT * OPS_W;            // 3 * MAGI_MAX_D
+        int* s_g = reinterpret_cast<int*>(s_cst + 3 * MAGI_MAX_D);
+        ChainCtl* s_ctl = reinterpret_cast<ChainCtl*>(s_cst + 3 * MAGI_MAX_D + 2);
+        static_assert(25 * 16 + 24 + PAR_COUNT + OPS_COUNT * OPS_W + 3 * MAGI_MAX_D + 2 + (sizeof(ChainCtl) + 7) / 8 <= MC_SM_DOUBLES, "decision scratch");
         const int chain = c0 + (int)blockIdx.x;
         if (chain < ch.n_chains) decide_block<DRIFT>(pb, ch, cfg, chain, parity, all_done, dsh, dshs, s_ctl, s_g, s_par, s_ops, s_cst);
         return;
@@ -640,12 +640,221 @@ void k_stream_mc(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     MC_STAMP(9);
 }
 
+// ---- streaming kernel for SEPARABLE drifts: no parameter, no plan, no drift evaluation in front of the tile stream ------------------
+// f_d(x, theta) = sum_k coef_{d,k}(theta) phi_{d,k}(x)  (DriftT<>::SEP): the operators are applied to the theta-FREE vectors xc_d and
+// phi_{d,k}(x) of the state a slot evaluates, which whoever set that state up has already written -- in the kernel's own operand order --
+// to the mirror ch.vop[slot parity] (SepLayout, magi_internal.h): the point phase's speculative next leaf, the decisions' subtree start,
+// k_mirror.  The point phase of THIS slot combines the products with coef(theta) (leap_point.h, point_block_sep): theta of the evaluated
+// state is complete by then (the decisions riding in this kernel finish it), so nothing in front of the tile stream hangs on the global
+// sums of the slot before.  Prologue = ONE round of loads (two operand slices, the chains' active bits), no transcendental, no second
+// barrier; k_stream / k_stream_mc spend 4.6 / 8 us of a workgroup's life deriving theta' and evaluating f there.
+// The 16 matrix-core columns of a pass are (basis function k, chain): up to 8 chains x 2 basis functions (CW = 8) or 16 chains x 1
+// (CW = 16); further basis planes are served by further workgroups on grid.z (they re-read the tile: rare shapes only).  One kernel family
+// for every chain count: a chain's arithmetic does not depend on the size of the batch it runs in.
+// Tile stream, lane layouts, LDS transposition and the rotation of the column sums through LDS are those of k_stream_mc above.
+template <int DRIFT, int CW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
+    using DR = DriftT<DRIFT>;
+    using SL = SepLayout<DRIFT>;
+    constexpr int D = DR::D, TB = MAGI_TB, PLANES = SL::planes(CW), PST = SL::PS_TOTAL;
+    const int all_done = ch.gctl->all_done;
+    kernarg_prefetch<sizeof(DevProblem) + sizeof(DevChains) + sizeof(SamplerCfgDev) + sizeof(int)>();
+    const int c0 = blockIdx.y * MC, z = blockIdx.z;
+    __shared__ __attribute__((aligned(16))) double smem[MC_SM_DOUBLES];
+    const int n_dec = (int)gridDim.x - pb.n_tasks;
+    if ((int)blockIdx.x < n_dec) {
+        if (z != 0) return;
+        double* dsh = smem;                                   // 25 * 16
+        double* dshs = dsh + 25 * 16;                         // 24
+        double* s_par = dshs + 24;                            // PAR_COUNT
+        double* s_ops = s_par + PAR_COUNT;                    // OPS_COUNT * OPS_W
+        double* s_cst = s_ops + OPS_COUNT * OPS_W;            // 3 * MAGI_MAX_D
+        int* s_g = reinterpret_cast<int*>(s_cst + 3 * MAGI_MAX_D);
+        ChainCtl* s_ctl = reinterpret_cast<ChainCtl*>(s_cst + 3 * MAGI_MAX_D + 2);
+        const int chain = c0 + (int)blockIdx.x;
+        if (chain < ch.n_chains) decide_block<DRIFT>(pb, ch, cfg, chain, parity, all_done, dsh, dshs, s_ctl, s_g, s_par, s_ops, s_cst);
+        return;
+    }
+    double* colsum = smem + MC_SM_CS;                                            // [matrix-core column][block column]: running column-type sums
+    const double2* vimg = reinterpret_cast<const double2*>(smem + MC_SM_V);    // [column pair][matrix-core column]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    double* stage = smem + MC_SM_ST + wave * 16 * MC_PITCH;
+    const int tix = (int)blockIdx.x - n_dec;
+    typedef const int __attribute__((address_space(4))) * const_int_ptr;
+    const_int_ptr tk = (const_int_ptr)(unsigned long long)(pb.tasks + 4 * (size_t)tix);
+    const int d = tk[0], kind = tk[1], bi = tk[2], bj = tk[3];
+    const int nch = ch.n_chains, ngrp = min(nch - c0, MC);
+    // which of the two products this (tile, basis plane) has: the row-type product multiplies xc (FH, FE: plane 0 only) or the basis
+    // plane z (FK); the column-type product xc (FH) or the basis plane z (FK, FE); diagonal blocks of FH / FK are complete by rows
+    const int nbd = DR::nbasis(d), gzd = (nbd * CW + 15) >> 4;
+    const bool phi_ok = z < gzd;
+    const bool rowt = (kind == TK_FK) ? phi_ok : (z == 0);
+    const bool colt = ((kind == TK_FE) || (bi != bj)) && ((kind == TK_FH) ? (z == 0) : phi_ok);
+    if (!rowt && !colt) return;
+    const bool rowphi = kind == TK_FK, colphi = kind != TK_FH;      // operand of the row- / column-type product is a basis plane (else xc)
+
+    // ---- the one round of loads in front of the tile stream: active bits, column slice (block bj), this wave's row slice (block bi) ----
+    const unsigned long long actb = __ballot(li < ngrp && ch.plan[(size_t)(parity ^ 1) * nch + min(c0 + li, nch - 1)].active != 0);
+    const int groups = (nch + 15) >> 4;
+    auto ldb = [](const double* sbase, unsigned boff) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(sbase) + boff); };
+    const double* mcol = ch.vop + vop_off(D, PLANES, pb.Np, groups, parity, (int)blockIdx.y, d, rowphi ? 1 + z : 0, bj * TB);     // (wave-uniform)
+    const double* mrow = ch.vop + vop_off(D, PLANES, pb.Np, groups, parity, (int)blockIdx.y, d, colphi ? 1 + z : 0, bi * TB);
+    const bool lcol = rowphi || li < CW, lrow = colphi || li < CW;      // (an xc plane holds CW columns: the other lanes of a 16-wide line load nothing)
+    double2 vv[4];
+    double wf[2][4];
+    {
+        const unsigned o = ((unsigned)(2 * (t >> 4)) * 16u + (unsigned)li) * 8u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            vv[k].x = (rowt && lcol) ? ldb(mcol, o + (unsigned)(32 * k) * 128u) : 0.0;
+            vv[k].y = (rowt && lcol) ? ldb(mcol, o + (unsigned)(32 * k + 1) * 128u) : 0.0;
+        }
+        const unsigned orow = ((unsigned)(32 * wave + lj) * 16u + (unsigned)li) * 8u;
+#pragma unroll
+        for (int cidx = 0; cidx < 2; ++cidx)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wf[cidx][q] = (colt && lrow) ? ldb(mrow, orow + (unsigned)(16 * cidx + 4 * q) * 128u) : 0.0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (all_done) return;
+
+    // ---- tile stream (as k_stream_mc): wave w owns rows [32 w, 32 w + 32); eight steps, phase p = s >> 1 works on column group (w + p) & 3 ----
+    const double2* A = reinterpret_cast<const double2*>(pb.tiles + (size_t)tix * TB * TB) + (size_t)(32 * wave + lj) * (TB / 2) + li;
+    auto ld = [&](int s, int q) { return A[(size_t)(16 * (s & 1) + 4 * q) * (TB / 2) + 16 * ((wave + (s >> 1)) & 3)]; };
+    double2 tl[MC_RING][4];
+#pragma unroll
+    for (int s = 0; s < MC_RING - 1; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tl[s][q] = ld(s, q);
+    __builtin_amdgcn_sched_barrier(0);
+    if (rowt) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) reinterpret_cast<double2*>(smem + MC_SM_V)[((t >> 4) + 16 * k) * MC + li] = vv[k];
+    }
+    __syncthreads();                 // operand image complete
+
+    mc_d4 accc[2], accr[2];
+    accr[0] = mc_d4{0.0, 0.0, 0.0, 0.0}; accr[1] = mc_d4{0.0, 0.0, 0.0, 0.0};
+    accc[0] = mc_d4{0.0, 0.0, 0.0, 0.0}; accc[1] = mc_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int cidx = s & 1, g = (wave + (s >> 1)) & 3;
+        if (s + MC_RING - 1 < 8) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tl[(s + MC_RING - 1) % MC_RING][q] = ld(s + MC_RING - 1, q);
+        }
+        double2 (&tt)[4] = tl[s % MC_RING];
+        if (cidx == 0 && s != 0 && colt) {
+            // take over the column sums of group g (register r of lane (li, lj) = column lj + 4 r, block columns 32 g + 2 li + {0, 1})
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double2 u = *reinterpret_cast<const double2*>(&colsum[(lj + 4 * r) * TB + 32 * g + 2 * li]);
+                accc[0][r] = u.x; accc[1][r] = u.y;
+            }
+        }
+        if (colt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                accc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[cidx][q], tt[q].x, accc[0], 0, 0, 0);
+                accc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[cidx][q], tt[q].y, accc[1], 0, 0, 0);
+            }
+        }
+        if (rowt) {
+            // transpose through the wave's LDS patch, then the row-type product
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(&stage[(4 * q + lj) * MC_PITCH + 2 * li]) = tt[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double2 b = *reinterpret_cast<const double2*>(&stage[li * MC_PITCH + 2 * (4 * q + lj)]);
+                const double2 v = vimg[(16 * g + 4 * q + lj) * MC + li];
+                accr[cidx] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, b.x, accr[cidx], 0, 0, 0);
+                accr[cidx] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, b.y, accr[cidx], 0, 0, 0);
+            }
+        }
+        if (cidx == 1 && colt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<double2*>(&colsum[(lj + 4 * r) * TB + 32 * g + 2 * li]) = double2{accc[0][r], accc[1][r]};
+            __syncthreads();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- partials.  Matrix-core column c of a product -> (basis function k, chain of the group) ----
+    auto col_chain = [&](bool phi, int c, int& k, int& cl) {
+        if (phi && CW == 8) { k = 2 * z + (c >> 3); cl = c & 7; }
+        else { k = phi ? z : 0; cl = c; }
+        return cl < ngrp && (!phi || k < nbd) && (phi || c < CW) && ((actb >> cl) & 1ull) != 0;
+    };
+    const size_t cstride = (size_t)PST * pb.nb * pb.Np;
+    if (rowt) {          // block row bi, slot bj; rows 32 wave + 16 cidx + li
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int k, cl;
+            const bool ok = col_chain(rowphi, lj + 4 * r, k, cl);
+            const int slot = kind == TK_FH ? SL::slot_hx(d) : kind == TK_FK ? SL::slot_kf(d, k) : SL::slot_ex(d);
+#pragma unroll
+            for (int cidx = 0; cidx < 2; ++cidx)
+                if (ok) ch.tpart[(size_t)(c0 + cl) * cstride + ((size_t)slot * pb.nb + bj) * pb.Np + bi * TB + 32 * wave + 16 * cidx + li] = accr[cidx][r];
+        }
+    }
+    if (colt) {          // block row bj, slot bi: complete in LDS after the last phase's barrier; thread = (column t >> 4, eight block columns)
+        int k, cl;
+        const bool ok = col_chain(colphi, t >> 4, k, cl);
+        const int col = 8 * (t & 15);
+        const int slot = kind == TK_FH ? SL::slot_hx(d) : kind == TK_FK ? SL::slot_kf(d, k) : SL::slot_etf(d, k);
+        if (ok) {
+            double2* dst = reinterpret_cast<double2*>(&ch.tpart[(size_t)(c0 + cl) * cstride + ((size_t)slot * pb.nb + bi) * pb.Np + bj * TB + col]);
+            const double2* src = reinterpret_cast<const double2*>(&colsum[(t >> 4) * TB + col]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) dst[kk] = src[kk];
+        }
+    }
+}
+
+// operand mirror (both slot parities) of the states in V_Q: API path and sampler start (the stream then finds its operands as it does
+// inside a trajectory)
+template <int DRIFT>
+__global__ __launch_bounds__(256) void k_mirror(DevProblem pb, DevChains ch) {
+    using DR = DriftT<DRIFT>;
+    if constexpr (DR::SEP) {
+        constexpr int D = DR::D, NBM = DR::NBMAX;
+        const int c = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= pb.N) return;
+        const double* q = ch.vec + vec_off(pb, c, V_Q);
+        double x[D], ph[D][NBM];
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) x[dd] = q[dd * pb.N + i];
+        DR::basis(x, ph);
+        const int cw = xop_width(ch.n_chains), groups = (ch.n_chains + 15) >> 4, cl = c & 15;
+        const int planes = 1 + (NBM * cw + 15) / 16;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) {
+                double* m0 = ch.vop + vop_off(D, planes, pb.Np, groups, b, c >> 4, dd, 0, i);
+                m0[cl] = x[dd] - pb.mu[dd];
+#pragma unroll
+                for (int k = 0; k < NBM; ++k)
+                    if (k < DR::nbasis(dd))
+                        m0[(size_t)(cw == 8 ? 1 + (k >> 1) : 1 + k) * pb.Np * 16 + (cw == 8 ? (k & 1) * 8 + cl : cl)] = ph[dd][k];
+            }
+    }
+}
+
 // ---- point kernel: the elementwise half of slot `parity` (leap_point.h), N / 16 workgroups per chain -------------------------
+template <int DRIFT> struct PointRes {
+    static constexpr int SEPN = DriftT<DRIFT>::SEP ? PT_POINTS * SepLayout<DRIFT>::PS_TOTAL : 0;
+    static constexpr int N = SEPN > PT_POINTS * PT_DSLOT * 4 ? SEPN : PT_POINTS * PT_DSLOT * 4;
+};
 template <int DRIFT>
 __global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains ch, int parity) {
-    __shared__ double res[PT_POINTS * PT_DSLOT * 4];
+    __shared__ double res[PointRes<DRIFT>::N];
     __shared__ double redk[64 * PART_K];
     __shared__ double s_mu[MAGI_MAX_D];
+    __shared__ double s_x[PT_POINTS * PT_DSLOT];
     // (flag and plan are fetched together and combined arithmetically: `a || b` would fetch b only after a has arrived --
     //  one more dependent round trip at the head of a 5 us kernel)
     const int all_done = ch.gctl->all_done;
@@ -653,7 +862,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains c
     kernarg_prefetch<sizeof(DevProblem) + sizeof(DevChains) + sizeof(int)>();
     const int gate = all_done | (lp.active ^ 1) | lp.skip;
     if (gate != 0) return;
-    point_block<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, res, redk, s_mu, parity ^ 1);
+    if constexpr (DriftT<DRIFT>::SEP) point_block_sep<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, res, redk, s_mu, s_x, parity ^ 1);
+    else point_block<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, res, redk, s_mu, parity ^ 1);
 }
 
 // load-only twin of k_stream's tile stream (bench.py's ceiling leg): every workgroup reads its 128 KB block with the same
@@ -703,8 +913,10 @@ template <int NC, int DRIFT>
 int launch_stream_nd(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s) {
     const DevProblem& pb = h->pb;
     const dim3 grid(pb.n_tasks + (with_decisions ? NC : 0), (n_chains + NC - 1) / NC);      // + one decision workgroup per chain
+    if constexpr (DriftT<DRIFT>::SEP) { (void)grid; return magi_fail(h, MAGI_E_STATE, "separable drifts run k_stream_sep"); } else {
     if (h->prof_e0) hipExtLaunchKernelGGL((k_stream<NC, DRIFT>), grid, dim3(64 * ST_WAVES), 0, s, h->prof_e0, h->prof_e1, 0, pb, h->ch, h->cfg, parity);
     else hipLaunchKernelGGL((k_stream<NC, DRIFT>), grid, dim3(64 * ST_WAVES), 0, s, pb, h->ch, h->cfg, parity);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("stream launch: ") + hipGetErrorString(e));
     return MAGI_OK;
@@ -726,9 +938,22 @@ template <int DRIFT>
 int launch_stream_mc(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s) {
     const DevProblem& pb = h->pb;
     const int groups = (n_chains + MC - 1) / MC;
+    if constexpr (DriftT<DRIFT>::SEP) {
+        // separable drifts: ONE kernel family for every chain count; grid.z = basis planes
+        if (n_chains <= 8) {
+            const dim3 grid(pb.n_tasks + (with_decisions ? MC : 0), groups, SepLayout<DRIFT>::gz(8));
+            if (h->prof_e0) hipExtLaunchKernelGGL((k_stream_sep<DRIFT, 8>), grid, dim3(256), 0, s, h->prof_e0, h->prof_e1, 0, pb, h->ch, h->cfg, parity);
+            else hipLaunchKernelGGL((k_stream_sep<DRIFT, 8>), grid, dim3(256), 0, s, pb, h->ch, h->cfg, parity);
+        } else {
+            const dim3 grid(pb.n_tasks + (with_decisions ? MC : 0), groups, SepLayout<DRIFT>::gz(16));
+            if (h->prof_e0) hipExtLaunchKernelGGL((k_stream_sep<DRIFT, 16>), grid, dim3(256), 0, s, h->prof_e0, h->prof_e1, 0, pb, h->ch, h->cfg, parity);
+            else hipLaunchKernelGGL((k_stream_sep<DRIFT, 16>), grid, dim3(256), 0, s, pb, h->ch, h->cfg, parity);
+        }
+    } else {
     const dim3 grid(pb.n_tasks + (with_decisions ? MC : 0), groups);
     if (h->prof_e0) hipExtLaunchKernelGGL((k_stream_mc<DRIFT>), grid, dim3(256), 0, s, h->prof_e0, h->prof_e1, 0, pb, h->ch, h->cfg, parity);
     else hipLaunchKernelGGL((k_stream_mc<DRIFT>), grid, dim3(256), 0, s, pb, h->ch, h->cfg, parity);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("stream (matrix-core) launch: ") + hipGetErrorString(e));
     return MAGI_OK;
@@ -744,8 +969,47 @@ bool magi_stream_family_mc(int n_chains) {
     return n_chains >= 3 || (e && std::string(e) == "mc");
 }
 
+bool magi_drift_separable(int drift) {
+#define MAGI_CALL(DR) return DriftT<DR>::SEP
+    MAGI_DRIFT_DISPATCH(drift, MAGI_CALL);
+#undef MAGI_CALL
+    return false;
+}
+
+template <int DRIFT> size_t sep_tpart_elems(const DevProblem& pb, int n) {
+    if constexpr (DriftT<DRIFT>::SEP) return (size_t)n * SepLayout<DRIFT>::PS_TOTAL * pb.nb * pb.Np;
+    else return 0;
+}
+template <int DRIFT> size_t sep_vop_elems(const DevProblem& pb, int n) {
+    if constexpr (DriftT<DRIFT>::SEP) return (size_t)2 * ((n + 15) / 16) * DriftT<DRIFT>::D * SepLayout<DRIFT>::planes(16) * pb.Np * 16;     // (CW = 16 has the most planes)
+    else return 0;
+}
+size_t magi_sep_tpart_elems(const DevProblem& pb, int n_chains) {
+#define MAGI_CALL(DR) return sep_tpart_elems<DR>(pb, n_chains)
+    MAGI_DRIFT_DISPATCH(pb.drift, MAGI_CALL);
+#undef MAGI_CALL
+    return 0;
+}
+size_t magi_sep_vop_elems(const DevProblem& pb, int n_chains) {
+#define MAGI_CALL(DR) return sep_vop_elems<DR>(pb, n_chains)
+    MAGI_DRIFT_DISPATCH(pb.drift, MAGI_CALL);
+#undef MAGI_CALL
+    return 0;
+}
+
+int magi_launch_mirror(magi_handle* h, int n_chains, hipStream_t s) {
+    if (!magi_drift_separable(h->pb.drift)) return MAGI_OK;
+    const dim3 g((h->pb.N + 255) / 256, n_chains), b(256);
+#define MAGI_CALL(DR) hipLaunchKernelGGL(k_mirror<DR>, g, b, 0, s, h->pb, h->ch)
+    MAGI_DRIFT_DISPATCH(h->pb.drift, MAGI_CALL);
+#undef MAGI_CALL
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("mirror launch: ") + hipGetErrorString(e));
+    return MAGI_OK;
+}
+
 int magi_launch_stream(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s) {
-    if (h->family_mc) {
+    if (h->family_mc || magi_drift_separable(h->pb.drift)) {
 #define MAGI_CALL(DR) return launch_stream_mc<DR>(h, n_chains, parity, with_decisions, s)
         MAGI_DRIFT_DISPATCH(h->pb.drift, MAGI_CALL);
 #undef MAGI_CALL

@@ -192,3 +192,172 @@ __device__ __forceinline__ void point_block(const DevProblem& pb, const DevChain
         for (int _i = 0; _i < 8; ++_i) reinterpret_cast<unsigned long long*>(ch.par + 40)[_i] = pt_st[_i];
 #endif
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Point phase of the SEPARABLE streaming path (k_stream_sep): the stream has left, per chain, the block partials of
+//     hx = FH xc,  ex = FE xc,  etf_k = FE^T phi_{d,k},  kf_k = FK phi_{d,k}        in tpart[chain][slot][other block][i]  (SepLayout)
+// -- products of theta-free vectors.  This phase adds them, combines etf = sum_k coef_k(theta) etf_k, kf = sum_k coef_k(theta) kf_k with
+// the parameters of the evaluated state (par, complete before this kernel starts), finishes the point exactly as point_block does, and
+// writes the operand mirror of the speculative next state: xc' = x' - mu and phi_{d,k}(x') for the stream of the NEXT slot.
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <int DRIFT>
+__device__ __forceinline__ void point_block_sep(const DevProblem& pb, const DevChains& ch, const LeafPlan& lp, int cc, int blk,
+                                                double* res /* PT_POINTS * PS_TOTAL */, double* redk /* 64 * PART_K */, double* s_mu /* MAGI_MAX_D */,
+                                                double* s_x /* PT_POINTS * PT_DSLOT */, int mirror_buf /* slot parity ^ 1 */) {
+    using GP = GridPoint<DRIFT>;
+    using DR = DriftT<DRIFT>;
+    using SL = SepLayout<DRIFT>;
+    constexpr int D = GP::D, P = GP::P, TB = MAGI_TB, PST = SL::PS_TOTAL, NBM = DR::NBMAX;
+    const unsigned t = threadIdx.x;
+    // finishing lanes: t < 64 = (component, point)
+    const int fpt = t & (PT_POINTS - 1), fd = (t / PT_POINTS) & (PT_DSLOT - 1);
+    const int fi = blk * PT_POINTS + fpt;
+    const bool fvalid = (t < 64) && (fd < D) && (fi < pb.N);
+    typename GP::Ops ops;
+    if (fvalid) ops = GP::load(pb, ch, lp, cc, fi, fd);
+    // product lanes: item = (slot, point); every used slot's nb block partials in flight together
+    {
+        const double* base = ch.tpart + (size_t)cc * PST * pb.nb * pb.Np;
+#pragma unroll
+        for (int it0 = 0; it0 < PT_POINTS * PST; it0 += PT_THREADS) {
+            const int item = it0 + (int)t;
+            const int pt = item & (PT_POINTS - 1), slot = item / PT_POINTS;
+            const int i = blk * PT_POINTS + pt;
+            if (slot < PST) {
+                double sum = 0.0;
+                if (SL::slot_used(slot) && i < pb.N) {
+                    const int b = i / TB, s0 = max(0, b - pb.wb), s1 = min(pb.nb - 1, b + pb.wb);
+                    const double* src = base + ((size_t)slot * pb.nb) * pb.Np + i;
+                    int sl = s0;
+                    for (; sl + 7 <= s1; sl += 8) {
+                        double u[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) u[k] = src[(size_t)(sl + k) * pb.Np];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) sum += u[k];
+                    }
+                    if (sl <= s1) {
+                        double u[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) u[k] = src[(size_t)min(sl + k, s1) * pb.Np];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) sum += (sl + k <= s1) ? u[k] : 0.0;
+                    }
+                }
+                res[pt * PST + slot] = sum;
+            }
+        }
+    }
+    if (t == PT_THREADS - 1) {
+#pragma unroll
+        for (int k = 0; k < MAGI_MAX_D; ++k) s_mu[k] = pb.mu[k];
+    }
+    __syncthreads();
+    if (t < 64) {
+        double* pk = redk + (size_t)t * PART_K;
+#pragma unroll
+        for (int k = 0; k < PART_K; ++k) pk[k] = 0.0;
+        double xn = 0.0;
+        if (fvalid) {
+            const double* r = res + fpt * PST;
+            const int N = pb.N, dimp = pb.dimp, d = fd, i = fi;
+            double* vb = ch.vec + vec_off(pb, cc, 0);
+            const int e = d * N + i;
+            const double mud = s_mu[fd];
+            double cf[D][NBM];
+            DR::coefs(ops.th, cf);
+            double f[D], g2[D], jt[D], tp[P];
+#pragma unroll
+            for (int k = 0; k < P; ++k) tp[k] = 0.0;
+            DR::f(ops.x, ops.th, f);
+            double hx = 0.0, ex = 0.0, etf = 0.0, kf = 0.0;
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) {
+                double kfd = 0.0, etd = 0.0;
+#pragma unroll
+                for (int k = 0; k < NBM; ++k) {
+                    if (k < DR::nbasis(dd)) {
+                        kfd = fma(cf[dd][k], r[SL::slot_kf(dd, k)], kfd);
+                        etd = fma(cf[dd][k], r[SL::slot_etf(dd, k)], etd);
+                    }
+                }
+                const double exd = r[SL::slot_ex(dd)];
+                g2[dd] = 2.0 * (kfd - exd);
+                if (d == dd) { hx = r[SL::slot_hx(dd)]; ex = exd; etf = etd; kf = kfd; }
+            }
+            DR::jt(ops.x, ops.th, g2, jt, tp);
+            double xd = ops.x[0], fdv = f[0], jtd = jt[0];
+#pragma unroll
+            for (int dd = 1; dd < D; ++dd) if (d == dd) { xd = ops.x[dd]; fdv = f[dd]; jtd = jt[dd]; }
+            pk[PK_T12] = (xd - mud) * hx + fdv * (kf - 2.0 * ex);
+            if (d == 0) {
+#pragma unroll
+                for (int k = 0; k < P; ++k) pk[PK_TP + k] = tp[k];
+            }
+            double d4 = 0.0;
+            if (!isnan(ops.y)) {
+                const double df = xd - ops.y;
+                pk[PK_SS + d] = df * df;
+                d4 = 2.0 * df / ops.sig2;
+            }
+            const double gx = -0.5 * (pb.beta_inv * (2.0 * hx - 2.0 * etf + jtd) + d4);
+            *(vb + (size_t)V_G * dimp + e) = gx;
+            if (lp.leaf) {
+                double* rho = vb + (size_t)V_RHOSUB * dimp;
+                double* ckp = vb + (size_t)V_CKP0 * dimp;
+                double* ckr = vb + (size_t)V_CKRHO0 * dimp;
+                const double pn = ops.phe + lp.hs * gx;
+                *(vb + (size_t)V_PLEAF * dimp + e) = pn;
+                const double rs = ops.rhoe + pn;
+                *(rho + e) = rs;
+                pk[PK_PP] = pn * pn;
+                if (lp.even) { *(ckp + (size_t)lp.ck_slot * dimp + e) = pn; *(ckr + (size_t)lp.ck_slot * dimp + e) = rs; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < lp.nchk) { const double df = rs - ops.crk[k]; pk[PK_DOT + 2 * k] = df * ops.cpk[k]; pk[PK_DOT + 2 * k + 1] = df * pn; }
+                const double pnext = pn + lp.hs * gx;
+                *(vb + (size_t)(V_P + (lp.cur ^ 1)) * dimp + e) = pnext;
+                xn = xd + lp.eps * pnext;
+                *(vb + (size_t)(V_Q + (lp.cur ^ 1)) * dimp + e) = xn;
+            }
+        }
+        // operand mirror of the speculative next state: the component lanes of a point exchange x' through LDS (one wave: its LDS
+        // operations execute in order, no workgroup barrier), then every lane writes xc' and the basis values of ITS component
+        if (lp.leaf) {
+            s_x[fpt * PT_DSLOT + fd] = xn;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (fvalid) {
+                double xq[D], ph[D][NBM];
+#pragma unroll
+                for (int dd = 0; dd < D; ++dd) xq[dd] = s_x[fpt * PT_DSLOT + dd];
+                DR::basis(xq, ph);
+                const int cw = xop_width(ch.n_chains), groups = (ch.n_chains + 15) >> 4, cl = cc & 15;
+                const int planes = 1 + (NBM * cw + 15) / 16;
+                double* m0 = ch.vop + vop_off(D, planes, pb.Np, groups, mirror_buf, cc >> 4, fd, 0, fi);
+                m0[cl] = xn - s_mu[fd];
+#pragma unroll
+                for (int dd = 0; dd < D; ++dd) {
+                    if (fd == dd) {
+#pragma unroll
+                        for (int k = 0; k < NBM; ++k)
+                            if (k < DR::nbasis(dd))
+                                m0[(size_t)(cw == 8 ? 1 + (k >> 1) : 1 + k) * pb.Np * 16 + (cw == 8 ? (k & 1) * 8 + cl : cl)] = ph[dd][k];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (t < 4 * PART_K) {
+        const int k = t >> 2, q = t & 3;
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += redk[(16 * q + u) * PART_K + k];
+        s += dpp_f64<0xB1>(s);
+        s += dpp_f64<0x4E>(s);
+        if (q == 0) *(&ch.part[((size_t)cc * PART_K + k) * ch.n_wg + blk]) = s;
+    }
+}

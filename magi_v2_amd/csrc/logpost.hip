@@ -278,7 +278,7 @@ int magi_launch_prepare(magi_handle* h, int n_chains, hipStream_t s) {
     hipLaunchKernelGGL(k_prepare, dim3(n_chains), dim3(64), 0, s, h->pb, h->ch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("prepare launch: ") + hipGetErrorString(e));
-    return MAGI_OK;
+    return magi_launch_mirror(h, n_chains, s);          // (separable drifts: the streaming kernel's operand mirror)
 }
 
 int magi_launch_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s) {

@@ -183,6 +183,7 @@ struct DevChains {
                           // order of the matrix-core streaming kernel (a block's slice of 16 chains is contiguous), at xop[s & 1]: written by whoever
                           // sets that state up during slot s - 1 (the point phase's speculative next leaf, the decisions' new subtree start,
                           // k_prepare) -- the stream needs no plan to find it
+    double* vop;          // separable drifts: operand mirror of the streaming kernel (SepLayout), written like xop; tpart then holds product slots
     double* par;          // [n_chains][PAR_COUNT] transformed parameters of the state in V_Q
     GlobalCtl* gctl;
     int n_chains;
@@ -471,8 +472,26 @@ __device__ __forceinline__ void drift_tt_g_acc(int drift, const double (&x)[MAGI
 // ------------------------------------------------------------------------------------------
 // Compile-time drifts for the sampler's kernels (D, P known -> no guards, no switch, small code)
 // ------------------------------------------------------------------------------------------
+// Separable form (SEP): f_d(x, theta) = sum_{k < nbasis(d)} coef_{d,k}(theta) phi_{d,k}(x).  The sampler's streaming kernel applies the
+// operators to the theta-FREE basis vectors phi_{d,k}(x) (written by whoever sets a state up) and the point phase combines the products
+// with coef(theta): the stream then needs no parameter that hangs on a global sum of the slot before (leap.hip, k_stream_sep).
+// basis / coefs fill [D][NBMAX] with zeros in unused entries.
 template <> struct DriftT<MAGI_DRIFT_SEIR3> {
     static constexpr int D = 3, P = 3;
+    static constexpr bool SEP = true;
+    static constexpr int NBMAX = 2;
+    __host__ __device__ static constexpr int nbasis(int d) { return d == 2 ? 1 : 2; }
+    static __device__ __forceinline__ void basis(const double (&x)[3], double (&ph)[3][2]) {
+        const double E = x[0], I = x[1], R = x[2], S = 1.0 - ((E + I) + R);
+        ph[0][0] = S * I; ph[0][1] = E;
+        ph[1][0] = E; ph[1][1] = I;
+        ph[2][0] = I; ph[2][1] = 0.0;
+    }
+    static __device__ __forceinline__ void coefs(const double (&th)[3], double (&c)[3][2]) {
+        c[0][0] = th[0]; c[0][1] = -th[2];
+        c[1][0] = th[2]; c[1][1] = -th[1];
+        c[2][0] = th[1]; c[2][1] = 0.0;
+    }
     static __device__ __forceinline__ void f(const double (&x)[3], const double (&th)[3], double (&o)[3]) {
         const double E = x[0], I = x[1], R = x[2], S = 1.0 - ((E + I) + R);
         o[0] = (th[0] * S * I) - (th[2] * E);
@@ -500,6 +519,22 @@ template <> struct DriftT<MAGI_DRIFT_SEIR3> {
 
 template <> struct DriftT<MAGI_DRIFT_SEIR4> {
     static constexpr int D = 4, P = 3;
+    static constexpr bool SEP = true;
+    static constexpr int NBMAX = 2;
+    __host__ __device__ static constexpr int nbasis(int d) { return (d == 0 || d == 3) ? 1 : 2; }
+    static __device__ __forceinline__ void basis(const double (&x)[4], double (&ph)[4][2]) {
+        const double S = x[0], E = x[1], I = x[2];
+        ph[0][0] = S * I; ph[0][1] = 0.0;
+        ph[1][0] = S * I; ph[1][1] = E;
+        ph[2][0] = E; ph[2][1] = I;
+        ph[3][0] = I; ph[3][1] = 0.0;
+    }
+    static __device__ __forceinline__ void coefs(const double (&th)[3], double (&c)[4][2]) {
+        c[0][0] = -th[0]; c[0][1] = 0.0;
+        c[1][0] = th[0]; c[1][1] = -th[2];
+        c[2][0] = th[2]; c[2][1] = -th[1];
+        c[3][0] = th[1]; c[3][1] = 0.0;
+    }
     static __device__ __forceinline__ void f(const double (&x)[4], const double (&th)[3], double (&o)[4]) {
         const double S = x[0], E = x[1], I = x[2];
         o[0] = -th[0] * S * I;
@@ -529,6 +564,22 @@ template <> struct DriftT<MAGI_DRIFT_SEIR4> {
 
 template <> struct DriftT<MAGI_DRIFT_SIRW> {
     static constexpr int D = 4, P = 5;
+    static constexpr bool SEP = true;
+    static constexpr int NBMAX = 3;
+    __host__ __device__ static constexpr int nbasis(int d) { return d < 2 ? 2 : 3; }
+    static __device__ __forceinline__ void basis(const double (&x)[4], double (&ph)[4][3]) {
+        const double S = x[0], I = x[1], R = x[2], W = x[3];
+        ph[0][0] = S * I; ph[0][1] = W; ph[0][2] = 0.0;
+        ph[1][0] = S * I; ph[1][1] = I; ph[1][2] = 0.0;
+        ph[2][0] = I; ph[2][1] = R; ph[2][2] = I * W;
+        ph[3][0] = R; ph[3][1] = I * W; ph[3][2] = W;
+    }
+    static __device__ __forceinline__ void coefs(const double (&th)[5], double (&c)[4][3]) {
+        c[0][0] = -th[0]; c[0][1] = th[4]; c[0][2] = 0.0;
+        c[1][0] = th[0]; c[1][1] = -th[1]; c[1][2] = 0.0;
+        c[2][0] = th[1]; c[2][1] = -th[2]; c[2][2] = th[3];
+        c[3][0] = th[2]; c[3][1] = -th[3]; c[3][2] = -th[4];
+    }
     static __device__ __forceinline__ void f(const double (&x)[4], const double (&th)[5], double (&o)[4]) {
         const double S = x[0], I = x[1], R = x[2], W = x[3];
         o[0] = -th[0] * S * I + th[4] * W;
@@ -557,6 +608,35 @@ template <> struct DriftT<MAGI_DRIFT_SIRW> {
         t[4] += (g[0] - g[3]) * W;
     }
 };
+
+// ------------------------------------------------------------------------------------------
+// Storage of the separable streaming path (k_stream_sep, leap.hip).
+//   product slots of component d (tpart[chain][slot][other block][Np]; unused k stay zero):
+//       d PS + 0: hx = FH xc     + 1: ex = FE xc     + 2 + k: etf_k = FE^T phi_{d,k}     + 2 + NBMAX + k: kf_k = FK phi_{d,k}
+//   operand mirror vop[slot parity][chain group][d][plane][Np][16]: plane 0 = xc_d of the group's chains (column = chain & 15),
+//       plane 1 + z = basis group z: 16 matrix-core columns = (k, chain); with at most 8 chains (CW = 8) two basis functions share a
+//       plane (k = 2 z + (col >> 3), chain = col & 7), else one per plane (k = z, chain = col).  Entries never written stay zero.
+// ------------------------------------------------------------------------------------------
+template <int DRIFT> struct SepLayout {
+    using DR = DriftT<DRIFT>;
+    static constexpr int D = DR::D, NBMAX = DR::NBMAX;
+    static constexpr int PS = 2 + 2 * NBMAX, PS_TOTAL = D * PS;
+    __host__ __device__ static constexpr int slot_hx(int d) { return d * PS; }
+    __host__ __device__ static constexpr int slot_ex(int d) { return d * PS + 1; }
+    __host__ __device__ static constexpr int slot_etf(int d, int k) { return d * PS + 2 + k; }
+    __host__ __device__ static constexpr int slot_kf(int d, int k) { return d * PS + 2 + NBMAX + k; }
+    __host__ __device__ static constexpr bool slot_used(int slot) {
+        const int d = slot / PS, r = slot - d * PS;
+        return r < 2 || ((r - 2) % NBMAX) < DR::nbasis(d);
+    }
+    __host__ __device__ static constexpr int gz(int cw) { return (NBMAX * cw + 15) / 16; }          // basis planes per component
+    __host__ __device__ static constexpr int planes(int cw) { return 1 + gz(cw); }
+    __host__ __device__ static constexpr int plane_of(int cw, int k) { return 1 + (cw == 8 ? (k >> 1) : k); }
+    __host__ __device__ static constexpr int col_of(int cw, int k, int chain_local) { return cw == 8 ? ((k & 1) * 8 + chain_local) : chain_local; }
+};
+__host__ __device__ inline size_t vop_off(int D, int planes, int Np, int groups, int b, int group, int d, int plane, int i) {
+    return (((((size_t)b * groups + group) * D + d) * planes + plane) * (size_t)Np + i) * 16;
+}
 
 // ------------------------------------------------------------------------------------------
 // reductions: 64-lane butterfly, then a fixed-order sum over the block's waves (deterministic)
@@ -773,7 +853,7 @@ struct magi_handle {
     int epoch = 0;
     long long* d_chain_ids = nullptr;
     double* d_fin = nullptr;         // [cap_chains][8] finalize outputs
-    size_t samples_cap = 0, diag_cap = 0;
+    size_t samples_cap = 0, diag_cap = 0, vop_elems = 0;
     // magi_sampler_profile: when set, the launchers of k_stream / k_point attach these events to the launch (hipExtLaunchKernel:
     // they take the kernel's own begin / end time stamps, what rocprofv3's kernel trace reports)
     hipEvent_t prof_e0 = nullptr, prof_e1 = nullptr;
@@ -816,6 +896,10 @@ int magi_launch_plan_eval(magi_handle* h, int n_chains, hipStream_t s);        /
 // build.hip: E = Ks M, H = Cs + M^T E for D dense [N][N] components (H overwrites Cs)
 int magi_fused_operators(magi_handle* h, int N, int D, double* dCs_inout_H, const double* dM, const double* dKs, double* dE);
 int magi_launch_prepare(magi_handle* h, int n_chains, hipStream_t s);   // fills par from V_Q
+int magi_launch_mirror(magi_handle* h, int n_chains, hipStream_t s);    // leap.hip: separable drifts: operand mirror (both slot parities) from V_Q
+bool magi_drift_separable(int drift);                                   // leap.hip
+size_t magi_sep_tpart_elems(const DevProblem& pb, int n_chains);        // leap.hip: doubles in tpart / vop for the separable path
+size_t magi_sep_vop_elems(const DevProblem& pb, int n_chains);
 int magi_launch_init_chains(magi_handle* h, const long long* d_chain_ids, hipStream_t s);
 int magi_ensure_chains(magi_handle* h, int n_chains);
 // build.hip: dense device matrices -> packed device storage (sym / transpose / band)

@@ -263,6 +263,37 @@ def matern_block_columns(I: np.ndarray, cols, phi1: float, phi2: float, v: float
     return Kappa, p_Kappa, Kappa_pp
 
 
+def matern_block_columns_accurate(I: np.ndarray, cols, phi1: float, phi2: float, v: float = 2.01):
+    """The same three blocks on columns ``cols`` through the cancellation-free forms (with u = c |s - t|,
+    c = sqrt(2 v) / phi2, A = phi1 2^(1-v) / Gamma(v)):
+        kappa = A u^v K_v(u),   d kappa / ds = -A c sgn(s - t) u^v K_{v-1}(u),   d^2 kappa / ds dt = A c^2 u^(v-1) (K_{v-1}(u) - u K_{v-2}(u))
+    -- mathematically the reference's expressions (magi_v2.py:790-815, via K_v' = -K_{v-1} - (v/u) K_v), without their loss of
+    digits at small lags (the reference's Kappa_pp carries ~2e-10 of its scale there, which K^-1 amplifies to 1e-5 in
+    K^-1 K = I at N = 8192).  Pinned to the 40-digit mpmath fixture G2 in tests/test_oracle_golden.py; it is the arbiter
+    where a check has to resolve below the reference's own rounding."""
+    from scipy.special import kv
+    I = np.asarray(I, dtype=np.float64).reshape(-1)
+    cols = np.asarray(cols, dtype=np.int64)
+    dlt = I[:, None] - I[cols][None, :]
+    diag = (np.arange(len(I))[:, None] == cols[None, :])
+    c = np.sqrt(2 * v) / phi2
+    u = c * np.abs(dlt)
+    u[diag] = 1.0                                    # (placeholder, overwritten below)
+    A = phi1 * 2.0 ** (1.0 - v) / gamma(v)
+    with np.errstate(invalid="ignore", over="ignore", under="ignore"):
+        uv = u ** v
+        Kv, Kv1, Kv2 = kv(v, u), kv(v - 1.0, u), kv(v - 2.0, u)
+        Kappa = A * uv * Kv
+        p_Kappa = -A * c * np.sign(dlt) * uv * Kv1
+        Kappa_pp = A * c * c * (u ** (v - 1.0)) * (Kv1 - u * Kv2)
+    for M in (Kappa, p_Kappa, Kappa_pp):
+        M[~np.isfinite(M)] = 0.0                     # (u beyond ~700: K underflows to 0, u^v overflows nowhere near: 0 * finite)
+    Kappa[diag] = phi1
+    p_Kappa[diag] = 0.0
+    Kappa_pp[diag] = v * phi1 / ((phi2 ** 2) * (v - 1))
+    return Kappa, p_Kappa, Kappa_pp
+
+
 def build_matrices(I: np.ndarray, phi1: float, phi2: float, v: float = 2.01):
     """``_build_matrices`` (magi_v2.py:774-823): returns (C_d, m_d, K_d)."""
     Kappa, p_Kappa, Kappa_pp = matern_blocks(I, phi1, phi2, v)

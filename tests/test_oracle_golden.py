@@ -66,6 +66,23 @@ def test_g2_matern_blocks_vs_mpmath(golden_dir):
         assert np.abs(K - g[f"{tag}_K"]).max() <= tol * np.abs(g[f"{tag}_K"]).max()
 
 
+def test_g2_column_evaluations_vs_mpmath_and_vs_the_full_blocks(golden_dir):
+    """The column-wise evaluations the N = 8192 build test uses as truth: ``matern_block_columns`` is the full-block code on
+    a subset of columns (equal bit for bit), ``matern_block_columns_accurate`` is pinned to the 40-digit mpmath blocks at 5e-14
+    of each block's scale -- four orders tighter than the reference's own Kappa_pp expression achieves (test above)."""
+    g = _load(golden_dir, "g2_mpmath.npz")
+    for tag in g["cases"]:
+        I = g[f"{tag}_I"]
+        p1, p2, v = g[f"{tag}_phi"]
+        cols = np.arange(len(I))[::3]
+        full = orc.matern_blocks(I.reshape(-1, 1), p1, p2, v)
+        for a, b in zip(orc.matern_block_columns(I, cols, p1, p2, v), full):
+            np.testing.assert_array_equal(a, b[:, cols])
+        for a, key in zip(orc.matern_block_columns_accurate(I, cols, p1, p2, v), ("Kappa", "pKappa", "Kappapp")):
+            truth = g[f"{tag}_{key}"]
+            np.testing.assert_allclose(a, truth[:, cols], rtol=0, atol=5e-14 * np.abs(truth).max(), err_msg=f"{tag} {key}")
+
+
 def test_g3_host_helpers_match_reference(golden_dir):
     g = _load(golden_dir, "g3_pipeline.npz")
     for name in ("seir3", "seir4"):
