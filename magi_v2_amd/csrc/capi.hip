@@ -140,7 +140,7 @@ int magi_ensure_chains(magi_handle* h, int n) {
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.part, sizeof(double) * PART_K * h->ch.n_wg * n));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.part, 0, sizeof(double) * PART_K * h->ch.n_wg * n));
         const bool sep = magi_drift_separable(h->pb.drift);
-        const size_t tpn = sep ? magi_sep_tpart_elems(h->pb, n) : (size_t)n * 4 * h->pb.D * h->pb.nb * h->pb.Np;
+        const size_t tpn = std::max(sep ? magi_sep_tpart_elems(h->pb, n) : (size_t)0, (size_t)n * 4 * h->pb.D * h->pb.nb * h->pb.Np);      // (either layout)
         MAGI_HIP_CHECK(h, hipMalloc(&h->ch.tpart, sizeof(double) * tpn));
         MAGI_HIP_CHECK(h, hipMemset(h->ch.tpart, 0, sizeof(double) * tpn));     // slots outside the block band stay zero
         const size_t opn = (size_t)2 * ((n + 15) / 16) * h->pb.D * h->pb.Np * 16;
@@ -162,7 +162,14 @@ int magi_ensure_chains(magi_handle* h, int n) {
     h->n_chains = n;
     h->ch.n_chains = n;
     h->family_mc = fam;
-    h->ch.mc = fam ? 1 : 0;
+    const bool sepk = fam && magi_drift_separable(h->pb.drift);
+    if ((h->ch.sep != 0) != sepk && h->ch.tpart) {      // the two streaming paths lay tpart out differently: slots the new one never writes must read zero
+        const size_t tpn = std::max(magi_drift_separable(h->pb.drift) ? magi_sep_tpart_elems(h->pb, h->cap_chains) : (size_t)0,
+                                    (size_t)h->cap_chains * 4 * h->pb.D * h->pb.nb * h->pb.Np);
+        MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.tpart, 0, sizeof(double) * tpn, h->stream));
+    }
+    h->ch.sep = sepk ? 1 : 0;
+    h->ch.mc = (fam && !sepk) ? 1 : 0;
     return MAGI_OK;
 }
 
@@ -399,10 +406,14 @@ static int logpost_grad_impl(magi_handle* h, bool fused, int n_chains, const dou
     MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.gctl, 0, sizeof(GlobalCtl), h->stream));
     if ((rc = magi_launch_prepare(h, n_chains, h->stream))) return rc;
     if (fused) {
-        if ((rc = magi_launch_plan_eval(h, n_chains, h->stream))) return rc;
-        if ((rc = magi_launch_stream(h, n_chains, 0, false, h->stream))) return rc;
-        if ((rc = magi_launch_point(h, n_chains, 0, h->stream))) return rc;
-        if ((rc = magi_launch_leap_finalize(h, n_chains, h->d_fin, h->stream))) return rc;
+        // (MAGI_FUSED_PARITY=1: evaluate as an ODD leapfrog slot does -- the streaming kernels walk their blocks backwards there and
+        //  read the other halves of the plan ring and of the operand mirrors; tests compare the two)
+        const char* pe = getenv("MAGI_FUSED_PARITY");
+        const int par = (pe && atoi(pe) == 1) ? 1 : 0;
+        if ((rc = magi_launch_plan_eval(h, n_chains, h->stream, par))) return rc;
+        if ((rc = magi_launch_stream(h, n_chains, par, false, h->stream))) return rc;
+        if ((rc = magi_launch_point(h, n_chains, par, h->stream))) return rc;
+        if ((rc = magi_launch_leap_finalize(h, n_chains, h->d_fin, h->stream, par))) return rc;
     } else {
         if ((rc = magi_launch_gradient(h, n_chains, h->stream))) return rc;
         if ((rc = magi_launch_finalize(h, n_chains, h->d_fin, h->stream))) return rc;

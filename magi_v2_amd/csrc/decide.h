@@ -113,7 +113,11 @@ __device__ __forceinline__ LeafPlan make_leaf_plan(const ChainCtl& c, unsigned l
 
 // All threads of a 256-thread workgroup call it; `parity` = slot whose stream is running next to these decisions
 // (they complete slot parity ^ 1 ... i.e. the slot the point phase executed last, and write plan[parity]).
-template <int DRIFT>
+// SEPK: the kernel these decisions ride in is k_stream_sep (they then also write the operand mirror of a state they set up).  A template
+// parameter, not a test of ch.sep: with the mirror pass merely COMPILED into the VALU kernels (never executed there) the one-chain SIRW
+// instantiation sampled wrong energies (tools/exp_family_hmc.py; round 3) -- the decision path is at the edge of what the register
+// allocator handles, and every instantiation is therefore held to an oracle run with deep trees (tests/test_sampler_gpu.py).
+template <int DRIFT, bool SEPK = false>
 __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChains& ch, const SamplerCfgDev& cfg, int chain, int parity, int all_done,
                                              double* sh /* 25*16 */, double* shs /* 24 */, ChainCtl* s_ctl, int* s_g, double* s_par /* PAR_COUNT */, double* s_ops /* OPS_COUNT * OPS_W */, double* s_cst /* 3 * MAGI_MAX_D: N_ds, LB, mu */) {
     const int tid = threadIdx.x;
@@ -489,13 +493,13 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
                     pw[e] = ph;
                     const double qn = q0[u] + eps * ph;
                     qw[e] = qn;
-                    if (!DriftT<DRIFT>::SEP && ch.mc && e < pb.ND) { const int dd = e / pb.N; ch.xop[xop_off(pb, ch.n_chains, parity ^ 1, chain, dd, e - dd * pb.N)] = qn; }   // (read by the next slot's stream)
+                    if (ch.mc && e < pb.ND) { const int dd = e / pb.N; ch.xop[xop_off(pb, ch.n_chains, parity ^ 1, chain, dd, e - dd * pb.N)] = qn; }   // (read by the next slot's stream)
                     v.rhosub[e] = 0.0;
                     if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par, true, s_cst + MAGI_MAX_D);
                 }
             }
         }
-        if constexpr (DriftT<DRIFT>::SEP) {
+        if constexpr (SEPK) {
             // operand mirror of the new state for the next slot's stream (k_stream_sep): xc and the basis values phi_{d,k} need ALL
             // components of a grid point, so the positions are formed again per point (same expressions, same rounding as above)
             using DR = DriftT<DRIFT>;

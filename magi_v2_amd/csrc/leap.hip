@@ -6,6 +6,7 @@
 // workgroup per chain, off the critical path, and the stream itself assumes "same subtree, next leaf".
 // (reference arithmetic: magi_v2.py:308-348)
 #include <cstdlib>
+#include <utility>
 
 #include "magi_internal.h"
 #include "leap_reduce.h"
@@ -646,12 +647,26 @@ void k_stream_mc(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
 // to the mirror ch.vop[slot parity] (SepLayout, magi_internal.h): the point phase's speculative next leaf, the decisions' subtree start,
 // k_mirror.  The point phase of THIS slot combines the products with coef(theta) (leap_point.h, point_block_sep): theta of the evaluated
 // state is complete by then (the decisions riding in this kernel finish it), so nothing in front of the tile stream hangs on the global
-// sums of the slot before.  Prologue = ONE round of loads (two operand slices, the chains' active bits), no transcendental, no second
-// barrier; k_stream / k_stream_mc spend 4.6 / 8 us of a workgroup's life deriving theta' and evaluating f there.
+// sums of the slot before.  Prologue = ONE round of loads (operand slices, the chains' active bits), no transcendental.
 // The 16 matrix-core columns of a pass are (basis function k, chain): up to 8 chains x 2 basis functions (CW = 8) or 16 chains x 1
-// (CW = 16); further basis planes are served by further workgroups on grid.z (they re-read the tile: rare shapes only).  One kernel family
-// for every chain count: a chain's arithmetic does not depend on the size of the batch it runs in.
+// (CW = 16); further basis planes are served by further workgroups on grid.z (they re-read the tile: rare shapes only).
+// Work per workgroup is EQUAL: the kernel is bound by the fp64 matrix pipe (measured 47-50 ns per v_mfma_f64_16x16x4_f64 and SIMD when
+// two or three waves keep it busy, tools/micro/mfma_rate.hip: 44 TFLOP/s, not the 78.6 of the data sheet), a diagonal block of FH / FK
+// has only the row-type product (half the MFMAs), and 544 blocks put a third workgroup on 32 of the 256 CUs -- so the task table
+// (pack.hip: stasks) pairs the two diagonal blocks FH_bb, FK_bb of a component into ONE task of 16 row-type steps: dense N = 1024,
+// D = 4: 480 + 32 = 512 tasks of 128 MFMAs per wave, two per CU.
 // Tile stream, lane layouts, LDS transposition and the rotation of the column sums through LDS are those of k_stream_mc above.
+// compile-time loop (the tile ring is a register array indexed by the step: the steps MUST be distinct straight-line code; a
+// `#pragma unroll` over a body of this size is only a request, and a loop the optimiser keeps puts the ring in scratch)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+#ifndef MAGI_SEP_RING
+#define MAGI_SEP_RING 3
+#endif
+constexpr int SEP_RING = MAGI_SEP_RING;
 template <int DRIFT, int CW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
@@ -662,9 +677,13 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     kernarg_prefetch<sizeof(DevProblem) + sizeof(DevChains) + sizeof(SamplerCfgDev) + sizeof(int)>();
     const int c0 = blockIdx.y * MC, z = blockIdx.z;
     __shared__ __attribute__((aligned(16))) double smem[MC_SM_DOUBLES];
-    const int n_dec = (int)gridDim.x - pb.n_tasks;
+    const int n_dec = (int)gridDim.x - pb.n_stasks;
     if ((int)blockIdx.x < n_dec) {
         if (z != 0) return;
+        const int chain = c0 + (int)blockIdx.x;
+        // (Measured as a function of its own -- not inlined, the kernel arguments re-read from the kernarg segment: the streaming body
+        //  then allocates for itself, 0 spills -- but the decisions then run 40 us: 500 scratch accesses, each a memory round trip next
+        //  to the saturating stream, and the slot waits for them: 45 us against 27.  Inlined, their spills stay off their hot path.)
         double* dsh = smem;                                   // 25 * 16
         double* dshs = dsh + 25 * 16;                         // 24
         double* s_par = dshs + 24;                            // PAR_COUNT
@@ -672,8 +691,7 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
         double* s_cst = s_ops + OPS_COUNT * OPS_W;            // 3 * MAGI_MAX_D
         int* s_g = reinterpret_cast<int*>(s_cst + 3 * MAGI_MAX_D);
         ChainCtl* s_ctl = reinterpret_cast<ChainCtl*>(s_cst + 3 * MAGI_MAX_D + 2);
-        const int chain = c0 + (int)blockIdx.x;
-        if (chain < ch.n_chains) decide_block<DRIFT>(pb, ch, cfg, chain, parity, all_done, dsh, dshs, s_ctl, s_g, s_par, s_ops, s_cst);
+        if (chain < ch.n_chains) decide_block<DRIFT, true>(pb, ch, cfg, chain, parity, all_done, dsh, dshs, s_ctl, s_g, s_par, s_ops, s_cst);
         return;
     }
     double* colsum = smem + MC_SM_CS;                                            // [matrix-core column][block column]: running column-type sums
@@ -683,26 +701,38 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     double* stage = smem + MC_SM_ST + wave * 16 * MC_PITCH;
     const int tix = (int)blockIdx.x - n_dec;
     typedef const int __attribute__((address_space(4))) * const_int_ptr;
-    const_int_ptr tk = (const_int_ptr)(unsigned long long)(pb.tasks + 4 * (size_t)tix);
-    const int d = tk[0], kind = tk[1], bi = tk[2], bj = tk[3];
+    const_int_ptr tk = (const_int_ptr)(unsigned long long)(pb.stasks + 8 * (size_t)tix);
+    const int d = tk[0], bi = tk[2], bj = tk[3];
+    int kind = tk[1], tile0 = tk[4], tile1 = tk[5], kind1 = tk[6];
     const int nch = ch.n_chains, ngrp = min(nch - c0, MC);
-    // which of the two products this (tile, basis plane) has: the row-type product multiplies xc (FH, FE: plane 0 only) or the basis
-    // plane z (FK); the column-type product xc (FH) or the basis plane z (FK, FE); diagonal blocks of FH / FK are complete by rows
+    // which products this (task, basis plane) has: the row-type product multiplies xc (FH, FE: plane 0 only) or the basis plane z (FK);
+    // the column-type product xc (FH) or the basis plane z (FK, FE); diagonal blocks of FH / FK are complete by rows.  A pair task
+    // (tile1 >= 0) is two diagonal blocks, FH then FK, of block row bi = bj.
     const int nbd = DR::nbasis(d), gzd = (nbd * CW + 15) >> 4;
     const bool phi_ok = z < gzd;
+    if (tile1 >= 0) {
+        const bool r0 = (kind == TK_FK) ? phi_ok : (z == 0), r1 = (kind1 == TK_FK) ? phi_ok : (z == 0);
+        if (!r0) { tile0 = tile1; kind = kind1; tile1 = -1; }       // (only the second block has work on this plane)
+        else if (!r1) tile1 = -1;
+    }
+    const bool pair = tile1 >= 0;
     const bool rowt = (kind == TK_FK) ? phi_ok : (z == 0);
     const bool colt = ((kind == TK_FE) || (bi != bj)) && ((kind == TK_FH) ? (z == 0) : phi_ok);
     if (!rowt && !colt) return;
     const bool rowphi = kind == TK_FK, colphi = kind != TK_FH;      // operand of the row- / column-type product is a basis plane (else xc)
+    const bool rowphi1 = kind1 == TK_FK;
 
-    // ---- the one round of loads in front of the tile stream: active bits, column slice (block bj), this wave's row slice (block bi) ----
+    // ---- the one round of loads in front of the tile stream: active bits, column slice(s) (block bj), this wave's row slice (block bi) ----
     const unsigned long long actb = __ballot(li < ngrp && ch.plan[(size_t)(parity ^ 1) * nch + min(c0 + li, nch - 1)].active != 0);
     const int groups = (nch + 15) >> 4;
-    auto ldb = [](const double* sbase, unsigned boff) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(sbase) + boff); };
+    typedef const double __attribute__((address_space(1))) * gd_ptr;
+    typedef const char __attribute__((address_space(1))) * gc_ptr;
+    auto ldb = [](const double* sbase, unsigned boff) -> double { return *(gd_ptr)((gc_ptr)(unsigned long long)sbase + boff); };
     const double* mcol = ch.vop + vop_off(D, PLANES, pb.Np, groups, parity, (int)blockIdx.y, d, rowphi ? 1 + z : 0, bj * TB);     // (wave-uniform)
+    const double* mcol1 = ch.vop + vop_off(D, PLANES, pb.Np, groups, parity, (int)blockIdx.y, d, rowphi1 ? 1 + z : 0, bj * TB);
     const double* mrow = ch.vop + vop_off(D, PLANES, pb.Np, groups, parity, (int)blockIdx.y, d, colphi ? 1 + z : 0, bi * TB);
-    const bool lcol = rowphi || li < CW, lrow = colphi || li < CW;      // (an xc plane holds CW columns: the other lanes of a 16-wide line load nothing)
-    double2 vv[4];
+    const bool lcol = rowphi || li < CW, lcol1 = rowphi1 || li < CW, lrow = colphi || li < CW;      // (an xc plane holds CW columns)
+    double2 vv[4], vv1[4];
     double wf[2][4];
     {
         const unsigned o = ((unsigned)(2 * (t >> 4)) * 16u + (unsigned)li) * 8u;
@@ -710,6 +740,8 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
         for (int k = 0; k < 4; ++k) {
             vv[k].x = (rowt && lcol) ? ldb(mcol, o + (unsigned)(32 * k) * 128u) : 0.0;
             vv[k].y = (rowt && lcol) ? ldb(mcol, o + (unsigned)(32 * k + 1) * 128u) : 0.0;
+            vv1[k].x = (pair && lcol1) ? ldb(mcol1, o + (unsigned)(32 * k) * 128u) : 0.0;
+            vv1[k].y = (pair && lcol1) ? ldb(mcol1, o + (unsigned)(32 * k + 1) * 128u) : 0.0;
         }
         const unsigned orow = ((unsigned)(32 * wave + lj) * 16u + (unsigned)li) * 8u;
 #pragma unroll
@@ -720,12 +752,22 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     __builtin_amdgcn_sched_barrier(0);
     if (all_done) return;
 
-    // ---- tile stream (as k_stream_mc): wave w owns rows [32 w, 32 w + 32); eight steps, phase p = s >> 1 works on column group (w + p) & 3 ----
-    const double2* A = reinterpret_cast<const double2*>(pb.tiles + (size_t)tix * TB * TB) + (size_t)(32 * wave + lj) * (TB / 2) + li;
-    auto ld = [&](int s, int q) { return A[(size_t)(16 * (s & 1) + 4 * q) * (TB / 2) + 16 * ((wave + (s >> 1)) & 3)]; };
-    double2 tl[MC_RING][4];
+    // ---- tile stream (as k_stream_mc): wave w owns rows [32 w, 32 w + 32) of a block; eight steps per block, phase p = s >> 1 works on
+    //      column group (w + p) & 3; a pair task streams its second block behind the first without a gap in the ring ----
+    // (explicitly GLOBAL pointers: through the lambdas below the compiler no longer infers the address space, and a flat load counts on
+    //  the LDS counter too -- every wait for a tile would also wait for the staging traffic, and the ring would run one step deep)
+    typedef double __attribute__((ext_vector_type(2))) d2v;
+    typedef const d2v __attribute__((address_space(1))) * gd2_ptr;
+    const gd2_ptr A0 = (gd2_ptr)(unsigned long long)(reinterpret_cast<const double2*>(pb.tiles + (size_t)tile0 * TB * TB) + (size_t)(32 * wave + lj) * (TB / 2) + li);
+    const gd2_ptr A1 = (gd2_ptr)(unsigned long long)(reinterpret_cast<const double2*>(pb.tiles + (size_t)max(tile1, 0) * TB * TB) + (size_t)(32 * wave + lj) * (TB / 2) + li);
+    auto ld = [&](int s, int q) -> double2 {
+        const d2v v = ((s >> 3) ? A1 : A0)[(size_t)(16 * (s & 1) + 4 * q) * (TB / 2) + 16 * ((wave + ((s & 7) >> 1)) & 3)];
+        return double2{v.x, v.y};
+    };
+    const int nsteps = pair ? 16 : 8;
+    double2 tl[SEP_RING][4];
 #pragma unroll
-    for (int s = 0; s < MC_RING - 1; ++s)
+    for (int s = 0; s < SEP_RING - 1; ++s)
 #pragma unroll
         for (int q = 0; q < 4; ++q) tl[s][q] = ld(s, q);
     __builtin_amdgcn_sched_barrier(0);
@@ -735,18 +777,47 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     }
     __syncthreads();                 // operand image complete
 
+    // matrix-core column c of a product -> (basis function k, chain of the group)
+    auto col_chain = [&](bool phi, int c, int& k, int& cl) {
+        if (phi && CW == 8) { k = 2 * z + (c >> 3); cl = c & 7; }
+        else { k = phi ? z : 0; cl = c; }
+        return cl < ngrp && (!phi || k < nbd) && (phi || c < CW) && ((actb >> cl) & 1ull) != 0;
+    };
+    const size_t cstride = (size_t)PST * pb.nb * pb.Np;
     mc_d4 accc[2], accr[2];
     accr[0] = mc_d4{0.0, 0.0, 0.0, 0.0}; accr[1] = mc_d4{0.0, 0.0, 0.0, 0.0};
     accc[0] = mc_d4{0.0, 0.0, 0.0, 0.0}; accc[1] = mc_d4{0.0, 0.0, 0.0, 0.0};
+    auto store_rows = [&](int knd, bool phi) {          // block row bi, slot bj; rows 32 wave + 16 cidx + li
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int cidx = s & 1, g = (wave + (s >> 1)) & 3;
-        if (s + MC_RING - 1 < 8) {
+        for (int r = 0; r < 4; ++r) {
+            int k, cl;
+            const bool ok = col_chain(phi, lj + 4 * r, k, cl);
+            const int slot = knd == TK_FH ? SL::slot_hx(d) : knd == TK_FK ? SL::slot_kf(d, k) : SL::slot_ex(d);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) tl[(s + MC_RING - 1) % MC_RING][q] = ld(s + MC_RING - 1, q);
+            for (int cidx = 0; cidx < 2; ++cidx)
+                if (ok) ch.tpart[(size_t)(c0 + cl) * cstride + ((size_t)slot * pb.nb + bj) * pb.Np + bi * TB + 32 * wave + 16 * cidx + li] = accr[cidx][r];
         }
-        double2 (&tt)[4] = tl[s % MC_RING];
-        if (cidx == 0 && s != 0 && colt) {
+    };
+    static_for<16>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        if (s < nsteps) {
+        constexpr int sl = s & 7, cidx = sl & 1;
+        const int g = (wave + (sl >> 1)) & 3;
+        if (s == 8) {
+            // second block of a pair: the first one's rows go out, its operand image is replaced
+            store_rows(kind, rowphi);
+            accr[0] = mc_d4{0.0, 0.0, 0.0, 0.0}; accr[1] = mc_d4{0.0, 0.0, 0.0, 0.0};
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) reinterpret_cast<double2*>(smem + MC_SM_V)[((t >> 4) + 16 * k) * MC + li] = vv1[k];
+            __syncthreads();
+        }
+        if (s + SEP_RING - 1 < nsteps) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tl[(s + SEP_RING - 1) % SEP_RING][q] = ld(s + SEP_RING - 1, q);
+        }
+        double2 (&tt)[4] = tl[s % SEP_RING];
+        if (cidx == 0 && sl != 0 && colt) {
             // take over the column sums of group g (register r of lane (li, lj) = column lj + 4 r, block columns 32 g + 2 li + {0, 1})
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -779,27 +850,12 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
                 *reinterpret_cast<double2*>(&colsum[(lj + 4 * r) * TB + 32 * g + 2 * li]) = double2{accc[0][r], accc[1][r]};
             __syncthreads();
         }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // ---- partials.  Matrix-core column c of a product -> (basis function k, chain of the group) ----
-    auto col_chain = [&](bool phi, int c, int& k, int& cl) {
-        if (phi && CW == 8) { k = 2 * z + (c >> 3); cl = c & 7; }
-        else { k = phi ? z : 0; cl = c; }
-        return cl < ngrp && (!phi || k < nbd) && (phi || c < CW) && ((actb >> cl) & 1ull) != 0;
-    };
-    const size_t cstride = (size_t)PST * pb.nb * pb.Np;
-    if (rowt) {          // block row bi, slot bj; rows 32 wave + 16 cidx + li
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int k, cl;
-            const bool ok = col_chain(rowphi, lj + 4 * r, k, cl);
-            const int slot = kind == TK_FH ? SL::slot_hx(d) : kind == TK_FK ? SL::slot_kf(d, k) : SL::slot_ex(d);
-#pragma unroll
-            for (int cidx = 0; cidx < 2; ++cidx)
-                if (ok) ch.tpart[(size_t)(c0 + cl) * cstride + ((size_t)slot * pb.nb + bj) * pb.Np + bi * TB + 32 * wave + 16 * cidx + li] = accr[cidx][r];
         }
-    }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+
+    // ---- partials ----
+    if (rowt) store_rows(pair ? kind1 : kind, pair ? rowphi1 : rowphi);
     if (colt) {          // block row bj, slot bi: complete in LDS after the last phase's barrier; thread = (column t >> 4, eight block columns)
         int k, cl;
         const bool ok = col_chain(colphi, t >> 4, k, cl);
@@ -862,8 +918,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains c
     kernarg_prefetch<sizeof(DevProblem) + sizeof(DevChains) + sizeof(int)>();
     const int gate = all_done | (lp.active ^ 1) | lp.skip;
     if (gate != 0) return;
-    if constexpr (DriftT<DRIFT>::SEP) point_block_sep<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, res, redk, s_mu, s_x, parity ^ 1);
-    else point_block<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, res, redk, s_mu, parity ^ 1);
+    if constexpr (DriftT<DRIFT>::SEP) {
+        if (ch.sep) { point_block_sep<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, res, redk, s_mu, s_x, parity ^ 1); return; }
+    }
+    point_block<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, res, redk, s_mu, parity ^ 1);
 }
 
 // load-only twin of k_stream's tile stream (bench.py's ceiling leg): every workgroup reads its 128 KB block with the same
@@ -878,24 +936,24 @@ __global__ __launch_bounds__(256) void k_read_tiles(const double2* __restrict__ 
 }
 
 // validation plan (magi_logpost_grad_fused / timing): slot 0 evaluates buffer 0 as is, no leapfrog
-__global__ void k_plan_eval(DevChains ch) {
+__global__ void k_plan_eval(DevChains ch, int parity) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ch.n_chains) return;
     LeafPlan prev{};
-    prev.active = 1; prev.skip = 1;           // what k_stream(parity 0) reads: "evaluate buffer 0 as is"
-    ch.plan[(size_t)ch.n_chains + c] = prev;
+    prev.active = 1; prev.skip = 1;           // what k_stream(parity) reads: "evaluate buffer 0 as is"
+    ch.plan[(size_t)(parity ^ 1) * ch.n_chains + c] = prev;
     LeafPlan p{};
-    p.active = 1;                             // what k_point(parity 0) executes: gradient only
-    ch.plan[c] = p;
+    p.active = 1;                             // what k_point(parity) executes: gradient only
+    ch.plan[(size_t)parity * ch.n_chains + c] = p;
 }
 
 template <int DRIFT>
-__global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_leap_finalize(DevProblem pb, DevChains ch, double* out) {
+__global__ __launch_bounds__(MAGI_TAIL_THREADS) void k_leap_finalize(DevProblem pb, DevChains ch, double* out, int parity) {
     __shared__ double sh[25 * 16];
     __shared__ double shs[16];
     const int c = blockIdx.x;
     double* vb = ch.vec + vec_off(pb, c, 0);
-    const LeafPlan lp = ch.plan[c];
+    const LeafPlan lp = ch.plan[(size_t)parity * ch.n_chains + c];
     double pre[RedLayout<DRIFT>::PER_WAVE];
     leap_reduce_issue<DRIFT>(ch, c, pre);
     double* par = ch.par + (size_t)c * PAR_COUNT;
@@ -913,7 +971,7 @@ template <int NC, int DRIFT>
 int launch_stream_nd(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s) {
     const DevProblem& pb = h->pb;
     const dim3 grid(pb.n_tasks + (with_decisions ? NC : 0), (n_chains + NC - 1) / NC);      // + one decision workgroup per chain
-    if constexpr (DriftT<DRIFT>::SEP) { (void)grid; return magi_fail(h, MAGI_E_STATE, "separable drifts run k_stream_sep"); } else {
+    {
     if (h->prof_e0) hipExtLaunchKernelGGL((k_stream<NC, DRIFT>), grid, dim3(64 * ST_WAVES), 0, s, h->prof_e0, h->prof_e1, 0, pb, h->ch, h->cfg, parity);
     else hipLaunchKernelGGL((k_stream<NC, DRIFT>), grid, dim3(64 * ST_WAVES), 0, s, pb, h->ch, h->cfg, parity);
     }
@@ -941,11 +999,11 @@ int launch_stream_mc(magi_handle* h, int n_chains, int parity, bool with_decisio
     if constexpr (DriftT<DRIFT>::SEP) {
         // separable drifts: ONE kernel family for every chain count; grid.z = basis planes
         if (n_chains <= 8) {
-            const dim3 grid(pb.n_tasks + (with_decisions ? MC : 0), groups, SepLayout<DRIFT>::gz(8));
+            const dim3 grid(pb.n_stasks + (with_decisions ? MC : 0), groups, SepLayout<DRIFT>::gz(8));
             if (h->prof_e0) hipExtLaunchKernelGGL((k_stream_sep<DRIFT, 8>), grid, dim3(256), 0, s, h->prof_e0, h->prof_e1, 0, pb, h->ch, h->cfg, parity);
             else hipLaunchKernelGGL((k_stream_sep<DRIFT, 8>), grid, dim3(256), 0, s, pb, h->ch, h->cfg, parity);
         } else {
-            const dim3 grid(pb.n_tasks + (with_decisions ? MC : 0), groups, SepLayout<DRIFT>::gz(16));
+            const dim3 grid(pb.n_stasks + (with_decisions ? MC : 0), groups, SepLayout<DRIFT>::gz(16));
             if (h->prof_e0) hipExtLaunchKernelGGL((k_stream_sep<DRIFT, 16>), grid, dim3(256), 0, s, h->prof_e0, h->prof_e1, 0, pb, h->ch, h->cfg, parity);
             else hipLaunchKernelGGL((k_stream_sep<DRIFT, 16>), grid, dim3(256), 0, s, pb, h->ch, h->cfg, parity);
         }
@@ -959,8 +1017,8 @@ int launch_stream_mc(magi_handle* h, int n_chains, int parity, bool with_decisio
     return MAGI_OK;
 }
 
-// Which kernel family streams the operator blocks: one or two chains -> the VALU kernel k_stream<1 | 2>, three or more -> the
-// matrix-core kernel k_stream_mc.  The two sum in different orders, so a chain's rounding depends on the size of the batch it
+// Which kernel family streams the operator blocks: one or two chains -> the VALU kernel k_stream<1 | 2>, three or more -> a
+// matrix-core kernel (k_stream_sep for separable drifts, k_stream_mc otherwise).  The two sum in different orders, so a chain's rounding depends on the size of the batch it
 // runs in (1-2 against >= 3).  MAGI_STREAM_FAMILY=mc routes EVERY batch size through the matrix-core kernel: a chain's samples
 // are then bit-identical whatever shares the GPU with it (uneven shards, e.g. 5 chains on 2 GPUs = 3 + 2), at the price of the
 // slower kernel for one or two chains.  Read at every sampler initialisation (magi_ensure_chains).
@@ -998,7 +1056,7 @@ size_t magi_sep_vop_elems(const DevProblem& pb, int n_chains) {
 }
 
 int magi_launch_mirror(magi_handle* h, int n_chains, hipStream_t s) {
-    if (!magi_drift_separable(h->pb.drift)) return MAGI_OK;
+    if (!h->ch.sep) return MAGI_OK;
     const dim3 g((h->pb.N + 255) / 256, n_chains), b(256);
 #define MAGI_CALL(DR) hipLaunchKernelGGL(k_mirror<DR>, g, b, 0, s, h->pb, h->ch)
     MAGI_DRIFT_DISPATCH(h->pb.drift, MAGI_CALL);
@@ -1009,7 +1067,7 @@ int magi_launch_mirror(magi_handle* h, int n_chains, hipStream_t s) {
 }
 
 int magi_launch_stream(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s) {
-    if (h->family_mc || magi_drift_separable(h->pb.drift)) {
+    if (h->family_mc) {          // (separable drifts: k_stream_sep, else k_stream_mc)
 #define MAGI_CALL(DR) return launch_stream_mc<DR>(h, n_chains, parity, with_decisions, s)
         MAGI_DRIFT_DISPATCH(h->pb.drift, MAGI_CALL);
 #undef MAGI_CALL
@@ -1037,16 +1095,16 @@ int magi_launch_read_tiles(magi_handle* h, int rev, hipStream_t s) {
     return MAGI_OK;
 }
 
-int magi_launch_plan_eval(magi_handle* h, int n_chains, hipStream_t s) {
-    hipLaunchKernelGGL(k_plan_eval, dim3((n_chains + 63) / 64), dim3(64), 0, s, h->ch);
+int magi_launch_plan_eval(magi_handle* h, int n_chains, hipStream_t s, int parity) {
+    hipLaunchKernelGGL(k_plan_eval, dim3((n_chains + 63) / 64), dim3(64), 0, s, h->ch, parity);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("plan launch: ") + hipGetErrorString(e));
     return MAGI_OK;
 }
 
-int magi_launch_leap_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s) {
+int magi_launch_leap_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s, int parity) {
     const dim3 g(n_chains), b(MAGI_TAIL_THREADS);
-#define MAGI_CALL(DR) hipLaunchKernelGGL(k_leap_finalize<DR>, g, b, 0, s, h->pb, h->ch, d_out)
+#define MAGI_CALL(DR) hipLaunchKernelGGL(k_leap_finalize<DR>, g, b, 0, s, h->pb, h->ch, d_out, parity)
     MAGI_DRIFT_DISPATCH(h->pb.drift, MAGI_CALL);
 #undef MAGI_CALL
     hipError_t e = hipGetLastError();

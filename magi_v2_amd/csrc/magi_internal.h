@@ -64,6 +64,9 @@ struct DevProblem {
     const double* tiles;   // [n_tasks][TB][TB]
     const int* tasks;      // [n_tasks][4] = {d, kind, bi, bj}
     int n_tasks;
+    const int* stasks;     // [n_stasks][8] = {d, kind, bi, bj, tile, tile1, kind1, 0}: the tasks of k_stream_sep -- the tasks above with the two
+                           // diagonal blocks FH_bb, FK_bb of a component (half the work each) paired into one (tile1 >= 0), so all are equal
+    int n_stasks;
     int nb;        // blocks per side, ceil(N / TB)
     int Np;        // nb * TB
     int wb;        // block half-band: blocks with |bi - bj| <= wb exist (nb when dense)
@@ -187,7 +190,9 @@ struct DevChains {
     double* par;          // [n_chains][PAR_COUNT] transformed parameters of the state in V_Q
     GlobalCtl* gctl;
     int n_chains;
-    int mc;               // the matrix-core streaming kernel serves this batch (three or more chains, or MAGI_STREAM_FAMILY=mc): keep xop up to date
+    int mc;               // the matrix-core streaming kernel k_stream_mc serves this batch (three or more chains of a NON-separable drift): keep xop up to date
+    int sep;              // the separable streaming kernel k_stream_sep serves this batch (separable drift and three or more chains, or
+                          // MAGI_STREAM_FAMILY=mc): keep vop up to date, tpart holds product slots (SepLayout)
     // outputs
     double* samples;      // [n_chains][num_results][dimp]
     double* d_step_size;  // diag arrays [n_chains][total]
@@ -884,7 +889,7 @@ int magi_launch_phase(magi_handle* h, int phase, int n_chains, hipStream_t s);
 int magi_launch_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s);
 int magi_launch_stream(magi_handle* h, int n_chains, int parity, bool with_decisions, hipStream_t s);   // k_stream: block mat-vecs of slot `parity` (+ decisions of the previous slot)
 int magi_launch_point(magi_handle* h, int n_chains, int parity, hipStream_t s);                            // k_point: leapfrog epilogue per grid point
-int magi_launch_leap_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s);
+int magi_launch_leap_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s, int parity = 0);
 int magi_leap_wgs(const DevProblem& pb);
 bool magi_stream_family_mc(int n_chains);        // leap.hip
 int magi_build_profile_get(double* flops, double* ms, long* calls);           // build.hip
@@ -892,7 +897,7 @@ int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const
                             const double* sd_phi2, const double* sig_loc, double nu, int iters, double lr, double jitter,
                             double* phi1, double* phi2, double* sig2, double* loss_trace);
 int magi_launch_read_tiles(magi_handle* h, int rev, hipStream_t s);                     // load-only pass over the packed operator blocks
-int magi_launch_plan_eval(magi_handle* h, int n_chains, hipStream_t s);        // plan: evaluate buffer 0, no leapfrog                                       // workgroups along the grid axis
+int magi_launch_plan_eval(magi_handle* h, int n_chains, hipStream_t s, int parity = 0);        // plan: evaluate buffer 0, no leapfrog                                       // workgroups along the grid axis
 // build.hip: E = Ks M, H = Cs + M^T E for D dense [N][N] components (H overwrites Cs)
 int magi_fused_operators(magi_handle* h, int N, int D, double* dCs_inout_H, const double* dM, const double* dKs, double* dE);
 int magi_launch_prepare(magi_handle* h, int n_chains, hipStream_t s);   // fills par from V_Q

@@ -145,6 +145,22 @@ int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double*
                         tasks.push_back(d); tasks.push_back(kind); tasks.push_back(bi); tasks.push_back(bj);
                     }
         const int n_tasks = (int)(tasks.size() / 4);
+        // tasks of the separable streaming kernel: as above, with FH_bb + FK_bb of a component paired (equal work per workgroup)
+        std::vector<int> stasks;
+        for (int i = 0; i < n_tasks; ++i) {
+            const int d = tasks[4 * i], kind = tasks[4 * i + 1], bi = tasks[4 * i + 2], bj = tasks[4 * i + 3];
+            int partner = -1;
+            if (kind != TK_FE && bi == bj) {
+                if (kind == TK_FK) continue;          // (taken by its FH partner)
+                for (int j = 0; j < n_tasks; ++j)
+                    if (tasks[4 * j] == d && tasks[4 * j + 1] == TK_FK && tasks[4 * j + 2] == bi && tasks[4 * j + 3] == bi) { partner = j; break; }
+            }
+            const int e[8] = {d, kind, bi, bj, i, partner, TK_FK, 0};
+            stasks.insert(stasks.end(), e, e + 8);
+        }
+        const int n_stasks = (int)(stasks.size() / 8);
+        const size_t n_task_ints = tasks.size();
+        tasks.insert(tasks.end(), stasks.begin(), stasks.end());
         const size_t telems = (size_t)n_tasks * MAGI_TB * MAGI_TB;
         if (telems > h->tiles_cap) {
             if (h->dTiles) (void)hipFree(h->dTiles);
@@ -179,6 +195,8 @@ int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double*
         pb.tiles = h->dTiles;
         pb.tasks = h->dTasks;
         pb.n_tasks = n_tasks;
+        pb.stasks = h->dTasks + n_task_ints;
+        pb.n_stasks = n_stasks;
         pb.nb = nb;
         pb.Np = nb * MAGI_TB;
         pb.wb = wb;

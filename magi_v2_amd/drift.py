@@ -158,6 +158,73 @@ def _emit_block(sp, printer, outputs: List[Tuple[str, object]], subs: dict, inde
     return "\n".join(lines)
 
 
+MAX_NB = 4        # basis functions per component the separable streaming path carries (more: the drift runs the general path)
+
+
+def _separate(sp, xs, ths, exprs):
+    """Separable form f_d(x, theta) = sum_k coef_{d,k}(theta) phi_{d,k}(x): per component a list of (coef, phi) sympy pairs, or None
+    when some term mixes x and theta inseparably (e.g. V x / (K + x) with K a parameter) or a component needs more than MAX_NB
+    basis functions.  Terms whose theta-dependent factors are equal up to a number share one basis function (c V - c V^3 / 3 + c R ->
+    coef c, phi = V - V^3 / 3 + R).  The sampler's streaming kernel for such drifts (csrc/leap.hip, k_stream_sep) applies the
+    operators to the theta-free phi's and the point phase combines the products with coef(theta)."""
+    xset, tset = set(xs), set(ths)
+    out = []
+    for e in exprs:
+        groups, order = {}, []
+        for term in sp.Add.make_args(sp.expand(e)):
+            if term == 0:
+                continue
+            coef, rest = term.as_independent(*xs, as_Add=False)
+            if rest.free_symbols & tset or coef.free_symbols & xset:
+                return None
+            num, sym = coef.as_coeff_Mul()
+            if sym not in groups:
+                groups[sym] = 0
+                order.append(sym)
+            groups[sym] = groups[sym] + num * rest
+        pairs = [(sym, sp.simplify(groups[sym])) for sym in order if sp.simplify(groups[sym]) != 0]
+        if len(pairs) > MAX_NB:
+            return None
+        out.append(pairs)
+    # numerical cross-check on random inputs: the separated form must reproduce f
+    rng = np.random.default_rng(7)
+    vals = {**{x: float(v) for x, v in zip(xs, rng.uniform(0.1, 0.9, len(xs)))}, **{t: float(v) for t, v in zip(ths, rng.uniform(0.3, 1.7, len(ths)))}}
+    for e, pairs in zip(exprs, out):
+        a = complex(sp.N(e.subs(vals)))
+        b = complex(sp.N(sum((c * ph for c, ph in pairs), sp.Integer(0)).subs(vals)))
+        if abs(a - b) > 1e-10 * max(1.0, abs(a)):
+            return None
+    return out
+
+
+def _sep_members(sp, pr, xs, ths, exprs, D: int, P: int, subs: dict) -> str:
+    """The DriftT<> members of the separable form (or SEP = false with inert members)."""
+    pairs = _separate(sp, xs, ths, exprs)
+    if pairs is None:
+        return f"""    static constexpr bool SEP = false;
+    static constexpr int NBMAX = 1;
+    __host__ __device__ static constexpr int nbasis(int) {{ return 0; }}
+    static __device__ __forceinline__ void basis(const double (&)[{D}], double (&ph)[{D}][1]) {{ for (int d = 0; d < {D}; ++d) ph[d][0] = 0.0; }}
+    static __device__ __forceinline__ void coefs(const double (&)[{P}], double (&c)[{D}][1]) {{ for (int d = 0; d < {D}; ++d) c[d][0] = 0.0; }}"""
+    nbmax = max(1, max(len(p_) for p_ in pairs))
+    nb = " : ".join([f"d == {d} ? {len(pairs[d])}" for d in range(D - 1)] + [f"{len(pairs[D - 1])}"]) if D > 1 else f"{len(pairs[0])}"
+    zero = sp.Integer(0)
+    b_out = [(f"ph[{d}][{k}] =", pairs[d][k][1] if k < len(pairs[d]) else zero) for d in range(D) for k in range(nbmax)]
+    c_out = [(f"c[{d}][{k}] =", pairs[d][k][0] if k < len(pairs[d]) else zero) for d in range(D) for k in range(nbmax)]
+    b_body = _emit_block(sp, pr, b_out, subs)
+    c_body = _emit_block(sp, pr, c_out, subs)
+    return f"""    // separable form f_d = sum_k coef_(d,k)(theta) phi_(d,k)(x)  (magi_v2_amd.drift._separate)
+    static constexpr bool SEP = true;
+    static constexpr int NBMAX = {nbmax};
+    __host__ __device__ static constexpr int nbasis(int d) {{ return {nb}; }}
+    static __device__ __forceinline__ void basis(const double (&x)[{D}], double (&ph)[{D}][{nbmax}]) {{
+{b_body}
+    }}
+    static __device__ __forceinline__ void coefs(const double (&th)[{P}], double (&c)[{D}][{nbmax}]) {{
+{c_body}
+    }}"""
+
+
 def _header(sp, xs, ths, exprs, D: int, P: int, tag: str) -> str:
     pr = _c_printer()
     xa = {xs[k]: sp.Symbol(f"x[{k}]") for k in range(D)}
@@ -172,6 +239,7 @@ def _header(sp, xs, ths, exprs, D: int, P: int, tag: str) -> str:
     jt_body = _emit_block(sp, pr, [(f"c[{k}] =", cJ[k]) for k in range(D)] + [(f"t[{p}] +=", cT[p]) for p in range(P)], subs)
     sel = " : ".join([f"d == {d} ? o[{d}]" for d in range(D - 1)] + [f"o[{D - 1}]"]) if D > 1 else "o[0]"
     selc = " : ".join([f"d == {d} ? c[{d}]" for d in range(D - 1)] + [f"c[{D - 1}]"]) if D > 1 else "c[0]"
+    sep_members = _sep_members(sp, pr, xs, ths, exprs, D, P, subs)
     return f"""// generated by magi_v2_amd.drift ({tag}) -- do not edit
 #pragma once
 #define MAGI_USER_D {D}
@@ -190,6 +258,7 @@ template <> struct DriftT<MAGI_DRIFT_USER> {{
     static __device__ __forceinline__ void jt(const double (&x)[{D}], const double (&th)[{P}], const double (&g)[{D}], double (&c)[{D}], double (&t)[{P}]) {{
 {jt_body}
     }}
+{sep_members}
 }};
 // runtime-switch entry points of the reference-order (three-phase) kernels
 __device__ __forceinline__ double user_drift_f(int d, const double* xp, const double* thp) {{

@@ -293,3 +293,60 @@ def test_checkpoint_resume_in_a_new_handle_continues_the_run_bit_for_bit(n_chain
         np.testing.assert_array_equal(a, b)
     for f in ("leapfrogs_taken", "tree_depth", "step_size", "target_log_prob", "is_accepted"):
         np.testing.assert_array_equal(getattr(dfull, f)[:, 7:], getattr(dpart, f)[:, 7:])
+
+
+@pytest.mark.parametrize("tag,chains", [("sirw_N41", 1), ("sirw_N41", 2), ("sirw_N41", 3), ("seir3_N161", 1), ("seir3_N161", 4), ("seir4_N81", 9)])
+def test_deep_trees_match_oracle_draw_for_draw_in_every_kernel_family(tag, chains):
+    """Every streaming-kernel instantiation a batch size selects (one chain: k_stream<1>, two: k_stream<2>, three or more: k_stream_sep
+    with its basis planes -- SIRW has three basis functions per component, i.e. a second plane on grid.z; nine chains: the 16-wide
+    mirror) against the oracle on transitions that BUILD trees: a first step size of 2e-3 gives trees of depth 5-9 from the first
+    transition on, where the reference's 0.1 makes the early transitions reject after one leapfrog -- and a rejected transition
+    hides whatever its leapfrogs computed (round 3: a one-chain SIRW build with wrong energies passed every default-step test)."""
+    g = load_g4(tag)
+    pr = problem_from_g4(g, None)
+    eng = engine_for(pr, None)
+    X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], np.ones(pr.P), pr.LB)
+    burnin, results, step0, depth = 4, 3, 2e-3, 7
+    cfg = eng.default_cfg(num_results=results, num_burnin_steps=burnin, step_size=step0, max_tree_depth=depth, stale_cache=0)
+    rep = lambda v: np.repeat(np.asarray(v)[None], chains, axis=0)
+    ids = list(range(20, 20 + chains))
+    eng.sampler_init(cfg, rep(X0), rep(s0), rep(t0), seed=808, chain_ids=ids)
+    lf, _ = eng.sampler_run(burnin + results)
+    Xs, sp, tp = eng.sampler_samples()
+    d = eng.sampler_diag()
+    eng.close()
+    assert lf == d.leapfrogs_taken.sum() and d.leapfrogs_taken.max() >= 31 and d.is_accepted.sum() >= chains
+    for i in sorted({0, chains - 1}):
+        trace = []
+        oX, osp, otp, info, _ = orc.sample_chain(pr, g["Xhat_init"], g["sigma_sqs_init"], np.ones(pr.P), results, burnin, seed=808, chain=ids[i],
+                                                 step_size=step0, stale_cache=False, trace=trace, max_tree_depth=depth)
+        np.testing.assert_array_equal(d.tree_depth[i], [r.depth for _, r, _ in trace])
+        np.testing.assert_array_equal(d.leapfrogs_taken[i], [r.leapfrogs for _, r, _ in trace])
+        np.testing.assert_array_equal(d.is_accepted[i], [int(r.is_accepted) for _, r, _ in trace])
+        np.testing.assert_allclose(d.target_log_prob[i], [r.target_log_prob for _, r, _ in trace], rtol=1e-8)
+        np.testing.assert_allclose(Xs[i], oX, rtol=0, atol=1e-8 * np.abs(oX).max())
+        np.testing.assert_allclose(tp[i], otp, rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["sirw_N41", "seir4_N81"])
+def test_fused_log_posterior_is_the_same_in_even_and_odd_slots(tag, monkeypatch):
+    """The streaming kernels walk their blocks backwards in odd leapfrog slots and read the other halves of the plan ring and of the
+    operand mirrors (MAGI_FUSED_PARITY=1 evaluates the fused log posterior that way): same values bit for bit, for one, two and five
+    states (the three kernel families)."""
+    g = load_g4(tag)
+    pr = problem_from_g4(g, None)
+    X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], np.linspace(0.7, 1.9, pr.P), pr.LB)
+    eng = engine_for(pr, None)
+    for n in (1, 2, 5):
+        X = X0[None] + 0.01 * np.random.default_rng(n).standard_normal((n,) + X0.shape)
+        sp, tp = np.repeat(s0[None], n, 0), np.repeat(t0[None], n, 0)
+        monkeypatch.setenv("MAGI_FUSED_PARITY", "0")
+        even = eng.logpost_grad(X, sp, tp, 1.0, fused=True)
+        monkeypatch.setenv("MAGI_FUSED_PARITY", "1")
+        odd = eng.logpost_grad(X, sp, tp, 1.0, fused=True)
+        ref = eng.logpost_grad(X, sp, tp, 1.0)
+        for a, b in zip(even, odd):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_allclose(even[0], ref[0], rtol=1e-10)
+        np.testing.assert_allclose(even[1], ref[1], rtol=0, atol=1e-10 * np.abs(ref[1]).max())
+    eng.close()

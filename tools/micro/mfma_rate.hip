@@ -1,0 +1,66 @@
+// Dev microbenchmark: issue rate of v_mfma_f64_16x16x4_f64 per SIMD with 1..3 waves per SIMD and 1, 2 or 4 accumulator chains
+// per wave (the streaming kernels accumulate 8 dependent MFMAs into one register block).  hipcc --offload-arch=gfx950 -O3
+#include <hip/hip_runtime.h>
+#include <cstdio>
+using d4 = __attribute__((ext_vector_type(4))) double;
+template <int CHAINS>
+__global__ __launch_bounds__(256) void k(double* out, int iters) {
+    d4 acc[CHAINS];
+    for (int c = 0; c < CHAINS; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+    }
+    double s = 0.0;
+    for (int c = 0; c < CHAINS; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+    if (s == 12345.678) out[0] = s;
+}
+template <int CHAINS>
+void run(int wgs_per_cu, int iters) {
+    double* out; hipMalloc(&out, 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int grid = 256 * wgs_per_cu;
+    hipLaunchKernelGGL(k<CHAINS>, dim3(grid), dim3(256), 0, 0, out, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<CHAINS>, dim3(grid), dim3(256), 0, 0, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double mfma_per_simd = (double)iters * CHAINS * wgs_per_cu;          // one wave of each workgroup per SIMD
+    printf("chains %d  waves/SIMD %d: %.1f us  -> %.1f ns per MFMA per SIMD (64 cycles at 2.4 GHz = 26.7 ns), %.1f TFLOP/s\n", CHAINS, wgs_per_cu, ms * 1e3,
+           ms * 1e6 / mfma_per_simd, 2048.0 * iters * CHAINS * 4 * grid / (ms * 1e-3) / 1e12);
+    hipFree(out);
+}
+// VALU: v_fma_f64 on 8 independent accumulators per lane
+__global__ __launch_bounds__(256) void kv(double* out, int iters) {
+    double acc[8];
+    for (int c = 0; c < 8; ++c) acc[c] = threadIdx.x * 1e-9 * c;
+    const double a = 1.0 + threadIdx.x * 1e-9, b = 1e-12;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = __builtin_fma(acc[c], a, b);
+    }
+    double s = 0.0;
+    for (int c = 0; c < 8; ++c) s += acc[c];
+    if (s == 12345.678) out[0] = s;
+}
+void run_valu(int wgs_per_cu, int iters) {
+    double* out; (void)hipMalloc(&out, 8);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int grid = 256 * wgs_per_cu;
+    hipLaunchKernelGGL(kv, dim3(grid), dim3(256), 0, 0, out, iters);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(kv, dim3(grid), dim3(256), 0, 0, out, iters);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("VALU fma_f64  waves/SIMD %d: %.1f us -> %.2f ns per wave-instruction per SIMD (4 cycles at 2.4 GHz = 1.67 ns), %.1f TFLOP/s\n", wgs_per_cu, ms * 1e3,
+           ms * 1e6 / ((double)iters * 8 * wgs_per_cu), 128.0 * iters * 8 * 4 * grid / (ms * 1e-3) / 1e12);
+    (void)hipFree(out);
+}
+int main() {
+    for (int w = 1; w <= 3; ++w) { run<1>(w, 4096); run<2>(w, 2048); run<4>(w, 1024); run<8>(w, 512); run<16>(w, 256); }
+    for (int w = 1; w <= 3; ++w) run_valu(w, 65536);
+    return 0;
+}
