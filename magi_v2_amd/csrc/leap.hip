@@ -664,11 +664,14 @@ template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 #ifndef MAGI_SEP_RING
-#define MAGI_SEP_RING 3
+#define MAGI_SEP_RING 2      // steps of tile loads per wave in the ring (2: 19.2 us, 3: 20.6, 4: 22.6 at 8 chains -- the kernel is bound by the fp64 matrix pipe, and a deeper ring only delays the first MFMA)
 #endif
 constexpr int SEP_RING = MAGI_SEP_RING;
+#ifndef MAGI_SEP_OCC
+#define MAGI_SEP_OCC 3
+#endif
 template <int DRIFT, int CW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAGI_SEP_OCC, MAGI_SEP_OCC)))
 void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     using DR = DriftT<DRIFT>;
     using SL = SepLayout<DRIFT>;
@@ -835,7 +838,9 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
         if (rowt) {
             // transpose through the wave's LDS patch, then the row-type product
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(&stage[(4 * q + lj) * MC_PITCH + 2 * li]) = tt[q];
+            for (int q = 0; q < 4; ++q) {
+                *reinterpret_cast<double2*>(&stage[(4 * q + lj) * MC_PITCH + 2 * li]) = tt[q];
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const double2 b = *reinterpret_cast<const double2*>(&stage[li * MC_PITCH + 2 * (4 * q + lj)]);
