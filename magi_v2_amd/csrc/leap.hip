@@ -828,6 +828,21 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
                 accc[0][r] = u.x; accc[1][r] = u.y;
             }
         }
+        // The transposition for the row-type product goes FIRST: its LDS round trip (write, transposed read, operand read) then runs
+        // under the column-type MFMAs, which take the tile piece straight from the registers.
+        double2 rb[4], rv[4];
+        if (rowt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(&stage[(4 * q + lj) * MC_PITCH + 2 * li]) = tt[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rb[q] = *reinterpret_cast<const double2*>(&stage[li * MC_PITCH + 2 * (4 * q + lj)]);
+                rv[q] = vimg[(16 * g + 4 * q + lj) * MC + li];
+            }
+        }
+#ifdef MAGI_SEP_PIPE
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (colt) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -836,17 +851,10 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
             }
         }
         if (rowt) {
-            // transpose through the wave's LDS patch, then the row-type product
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                *reinterpret_cast<double2*>(&stage[(4 * q + lj) * MC_PITCH + 2 * li]) = tt[q];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double2 b = *reinterpret_cast<const double2*>(&stage[li * MC_PITCH + 2 * (4 * q + lj)]);
-                const double2 v = vimg[(16 * g + 4 * q + lj) * MC + li];
-                accr[cidx] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, b.x, accr[cidx], 0, 0, 0);
-                accr[cidx] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, b.y, accr[cidx], 0, 0, 0);
+                accr[cidx] = __builtin_amdgcn_mfma_f64_16x16x4f64(rv[q].x, rb[q].x, accr[cidx], 0, 0, 0);
+                accr[cidx] = __builtin_amdgcn_mfma_f64_16x16x4f64(rv[q].y, rb[q].y, accr[cidx], 0, 0, 0);
             }
         }
         if (cidx == 1 && colt) {
