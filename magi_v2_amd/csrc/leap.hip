@@ -676,6 +676,13 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     using DR = DriftT<DRIFT>;
     using SL = SepLayout<DRIFT>;
     constexpr int D = DR::D, TB = MAGI_TB, PLANES = SL::planes(CW), PST = SL::PS_TOTAL;
+#ifdef MAGI_SEP_STAMPS      // dev: 100 MHz time stamps of ONE task's workgroup, kept in scalar registers, written at the end to par[40 ..] of chain 0 (tools/exp_sep_stamps.py)
+    unsigned long long sst[16] = {0ull};
+#define SEP_STAMP(i) do { sst[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SEP_STAMP(i) do { } while (0)
+#endif
+    SEP_STAMP(0);
     const int all_done = ch.gctl->all_done;
     kernarg_prefetch<sizeof(DevProblem) + sizeof(DevChains) + sizeof(SamplerCfgDev) + sizeof(int)>();
     const int c0 = blockIdx.y * MC, z = blockIdx.z;
@@ -707,6 +714,7 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     const_int_ptr tk = (const_int_ptr)(unsigned long long)(pb.stasks + 8 * (size_t)tix);
     const int d = tk[0], bi = tk[2], bj = tk[3];
     int kind = tk[1], tile0 = tk[4], tile1 = tk[5], kind1 = tk[6];
+    SEP_STAMP(1);              // task descriptor known
     const int nch = ch.n_chains, ngrp = min(nch - c0, MC);
     // which products this (task, basis plane) has: the row-type product multiplies xc (FH, FE: plane 0 only) or the basis plane z (FK);
     // the column-type product xc (FH) or the basis plane z (FK, FE); diagonal blocks of FH / FK are complete by rows.  A pair task
@@ -725,8 +733,35 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     const bool rowphi = kind == TK_FK, colphi = kind != TK_FH;      // operand of the row- / column-type product is a basis plane (else xc)
     const bool rowphi1 = kind1 == TK_FK;
 
+    // ---- tile stream (as k_stream_mc): wave w owns rows [32 w, 32 w + 32) of a block; eight steps per block, phase p = s >> 1 works on
+    //      column group (w + p) & 3; a pair task streams its second block behind the first without a gap in the ring ----
+    // (explicitly GLOBAL pointers: through the lambdas below the compiler no longer infers the address space, and a flat load counts on
+    //  the LDS counter too -- every wait for a tile would also wait for the staging traffic, and the ring would run one step deep)
+    typedef double __attribute__((ext_vector_type(2))) d2v;
+    typedef const d2v __attribute__((address_space(1))) * gd2_ptr;
+    const gd2_ptr A0 = (gd2_ptr)(unsigned long long)(reinterpret_cast<const double2*>(pb.tiles + (size_t)tile0 * TB * TB) + (size_t)(32 * wave + lj) * (TB / 2) + li);
+    const gd2_ptr A1 = (gd2_ptr)(unsigned long long)(reinterpret_cast<const double2*>(pb.tiles + (size_t)max(tile1, 0) * TB * TB) + (size_t)(32 * wave + lj) * (TB / 2) + li);
+    auto ld = [&](int s, int q) -> double2 {
+        const d2v v = ((s >> 3) ? A1 : A0)[(size_t)(16 * (s & 1) + 4 * q) * (TB / 2) + 16 * ((wave + ((s & 7) >> 1)) & 3)];
+        return double2{v.x, v.y};
+    };
+    // (The ring goes out FIRST, right behind the task descriptor, then the operand slices.  Device time stamps of a workgroup
+    //  (-DMAGI_SEP_STAMPS, tools/exp_sep_stamps.py; 8 chains, kernel 19-20 us): task known 0.5 us after entry, the ~30 vector-memory
+    //  instructions of the prologue take 2.4 us to ISSUE on a CU whose other waves are streaming -- which is why a deeper ring makes
+    //  the kernel slower (3 steps: 23.7 us, 4: 29.8) --, operands in LDS at 3.4 us, then 1.0-1.8 us per step (4 KB per wave and step:
+    //  the CU's 8 waves draw ~26 GB/s, the device 6.7 TB/s: the steps run at the memory system's rate), stores out at 15 us.)
+    const int nsteps = pair ? 16 : 8;
+    double2 tl[SEP_RING][4];
+#pragma unroll
+    for (int s = 0; s < SEP_RING - 1; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tl[s][q] = ld(s, q);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- the one round of loads in front of the tile stream: active bits, column slice(s) (block bj), this wave's row slice (block bi) ----
-    const unsigned long long actb = __ballot(li < ngrp && ch.plan[(size_t)(parity ^ 1) * nch + min(c0 + li, nch - 1)].active != 0);
+    // (the chains' active flags are LOADED here and balloted at the stores: a ballot in front of the operand loads made every workgroup
+    //  wait 1.5 us for the plan's round trip before its first load -- device time stamps, tools/exp_sep_stamps.py)
+    typedef const int __attribute__((address_space(1))) * gi_ptr;       // (a GLOBAL load: a flat one would also sit on the LDS counter)
+    const int act_flag = *(gi_ptr)(unsigned long long)&ch.plan[(size_t)(parity ^ 1) * nch + min(c0 + li, nch - 1)].active;
     const int groups = (nch + 15) >> 4;
     typedef const double __attribute__((address_space(1))) * gd_ptr;
     typedef const char __attribute__((address_space(1))) * gc_ptr;
@@ -753,33 +788,19 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
             for (int q = 0; q < 4; ++q) wf[cidx][q] = (colt && lrow) ? ldb(mrow, orow + (unsigned)(16 * cidx + 4 * q) * 128u) : 0.0;
     }
     __builtin_amdgcn_sched_barrier(0);
+    SEP_STAMP(2);              // operand loads issued
     if (all_done) return;
 
-    // ---- tile stream (as k_stream_mc): wave w owns rows [32 w, 32 w + 32) of a block; eight steps per block, phase p = s >> 1 works on
-    //      column group (w + p) & 3; a pair task streams its second block behind the first without a gap in the ring ----
-    // (explicitly GLOBAL pointers: through the lambdas below the compiler no longer infers the address space, and a flat load counts on
-    //  the LDS counter too -- every wait for a tile would also wait for the staging traffic, and the ring would run one step deep)
-    typedef double __attribute__((ext_vector_type(2))) d2v;
-    typedef const d2v __attribute__((address_space(1))) * gd2_ptr;
-    const gd2_ptr A0 = (gd2_ptr)(unsigned long long)(reinterpret_cast<const double2*>(pb.tiles + (size_t)tile0 * TB * TB) + (size_t)(32 * wave + lj) * (TB / 2) + li);
-    const gd2_ptr A1 = (gd2_ptr)(unsigned long long)(reinterpret_cast<const double2*>(pb.tiles + (size_t)max(tile1, 0) * TB * TB) + (size_t)(32 * wave + lj) * (TB / 2) + li);
-    auto ld = [&](int s, int q) -> double2 {
-        const d2v v = ((s >> 3) ? A1 : A0)[(size_t)(16 * (s & 1) + 4 * q) * (TB / 2) + 16 * ((wave + ((s & 7) >> 1)) & 3)];
-        return double2{v.x, v.y};
-    };
-    const int nsteps = pair ? 16 : 8;
-    double2 tl[SEP_RING][4];
-#pragma unroll
-    for (int s = 0; s < SEP_RING - 1; ++s)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) tl[s][q] = ld(s, q);
-    __builtin_amdgcn_sched_barrier(0);
+    SEP_STAMP(3);              // ring issued
     if (rowt) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) reinterpret_cast<double2*>(smem + MC_SM_V)[((t >> 4) + 16 * k) * MC + li] = vv[k];
     }
+    SEP_STAMP(4);              // operands arrived, image written
     __syncthreads();                 // operand image complete
+    SEP_STAMP(5);
 
+    unsigned long long actb = 0ull;          // bit c: chain c of the group takes part in this slot (set before the first store)
     // matrix-core column c of a product -> (basis function k, chain of the group)
     auto col_chain = [&](bool phi, int c, int& k, int& cl) {
         if (phi && CW == 8) { k = 2 * z + (c >> 3); cl = c & 7; }
@@ -808,6 +829,7 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
         const int g = (wave + (sl >> 1)) & 3;
         if (s == 8) {
             // second block of a pair: the first one's rows go out, its operand image is replaced
+            actb = __ballot(li < ngrp && act_flag != 0);
             store_rows(kind, rowphi);
             accr[0] = mc_d4{0.0, 0.0, 0.0, 0.0}; accr[1] = mc_d4{0.0, 0.0, 0.0, 0.0};
             __syncthreads();
@@ -865,9 +887,11 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
         }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (s < 8) SEP_STAMP(6 + s);      // steps 0 .. 7 done: 6 .. 13
     });
 
     // ---- partials ----
+    actb = __ballot(li < ngrp && act_flag != 0);
     if (rowt) store_rows(pair ? kind1 : kind, pair ? rowphi1 : rowphi);
     if (colt) {          // block row bj, slot bi: complete in LDS after the last phase's barrier; thread = (column t >> 4, eight block columns)
         int k, cl;
@@ -881,6 +905,13 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
             for (int kk = 0; kk < 4; ++kk) dst[kk] = src[kk];
         }
     }
+#ifdef MAGI_SEP_STAMPS
+    SEP_STAMP(14);
+    __builtin_amdgcn_s_waitcnt(0);
+    SEP_STAMP(15);             // stores retired
+    if (tix == (MAGI_SEP_STAMPS) && blockIdx.y == 0 && z == 0 && threadIdx.x == 0)
+        for (int i_ = 0; i_ < 16; ++i_) reinterpret_cast<unsigned long long*>(ch.par + 40)[i_ < 12 ? i_ : i_] = sst[i_];
+#endif
 }
 
 // operand mirror (both slot parities) of the states in V_Q: API path and sampler start (the stream then finds its operands as it does

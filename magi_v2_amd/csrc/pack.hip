@@ -32,6 +32,35 @@ __global__ void k_pack(const double* __restrict__ src, double* __restrict__ dst,
     dst[((size_t)d * N + i) * ld + k] = v;
 }
 
+// The same for DENSE storage (row i holds columns 0 .. ld): 32 x 32 tiles through LDS, so that the transposed operand A[j][i] of
+// the symmetrised / transposed copies is read along its rows too (k_pack reads it down a column: 2.3 ms per N = 8192 x 4 stack,
+// 0.9 TB/s -- four such passes were 9 ms of the 336 ms build).  grid (ceil(ld / 32), ceil(N / 32), D), block (32, 8).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_pack_dense(const double* __restrict__ src, double* __restrict__ dst, int N, int ld, int band) {
+    __shared__ double t1[32][33], t2[32][33];
+    const double* A = src + (size_t)blockIdx.z * N * N;
+    const int j0 = blockIdx.x * 32, i0 = blockIdx.y * 32, tx = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ty = threadIdx.y + 8 * r;
+        const int i = i0 + ty, j = j0 + tx;                 // this tile
+        if (MODE != PACK_TRANS) t1[ty][tx] = (i < N && j < N) ? A[(size_t)i * N + j] : 0.0;
+        const int it = j0 + ty, jt = i0 + tx;               // the partner tile: rows j0.., columns i0..
+        if (MODE != PACK_COPY) t2[ty][tx] = (it < N && jt < N) ? A[(size_t)it * N + jt] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ty = threadIdx.y + 8 * r;
+        const int i = i0 + ty, j = j0 + tx;
+        if (i >= N || j >= ld) continue;
+        double v = 0.0;
+        if (j < N && (band < 0 || abs(i - j) <= band))
+            v = MODE == PACK_COPY ? t1[ty][tx] : MODE == PACK_TRANS ? t2[tx][ty] : 0.5 * (t1[ty][tx] + t2[tx][ty]);
+        dst[((size_t)blockIdx.z * N + i) * ld + j] = v;
+    }
+}
+
 // one TB x TB block of FH / FK / FE per workgroup -> packed tile storage, zero beyond N and beyond the band
 __global__ __launch_bounds__(256) void k_pack_tiles(const double* __restrict__ H, const double* __restrict__ K, const double* __restrict__ E,
                                                     const int* __restrict__ tasks, double* __restrict__ tiles, int N, int fb) {
@@ -120,10 +149,19 @@ int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double*
     }
     const int mask = bandsize >= 0 ? bandsize : -1;
     dim3 block(256), grid((ld + 255) / 256, N, D);
-    hipLaunchKernelGGL(k_pack<PACK_SYM>, grid, block, 0, h->stream, dC_inv, h->dCsym, N, ld, mask, banded ? 1 : 0);
-    hipLaunchKernelGGL(k_pack<PACK_COPY>, grid, block, 0, h->stream, dM, h->dM, N, ld, mask, banded ? 1 : 0);
-    hipLaunchKernelGGL(k_pack<PACK_TRANS>, grid, block, 0, h->stream, dM, h->dMt, N, ld, mask, banded ? 1 : 0);
-    hipLaunchKernelGGL(k_pack<PACK_SYM>, grid, block, 0, h->stream, dK_inv, h->dKsym, N, ld, mask, banded ? 1 : 0);
+    const dim3 dblock(32, 8);
+    auto dgrid = [&](int width) { return dim3((width + 31) / 32, (N + 31) / 32, D); };
+    if (banded) {
+        hipLaunchKernelGGL(k_pack<PACK_SYM>, grid, block, 0, h->stream, dC_inv, h->dCsym, N, ld, mask, 1);
+        hipLaunchKernelGGL(k_pack<PACK_COPY>, grid, block, 0, h->stream, dM, h->dM, N, ld, mask, 1);
+        hipLaunchKernelGGL(k_pack<PACK_TRANS>, grid, block, 0, h->stream, dM, h->dMt, N, ld, mask, 1);
+        hipLaunchKernelGGL(k_pack<PACK_SYM>, grid, block, 0, h->stream, dK_inv, h->dKsym, N, ld, mask, 1);
+    } else {
+        hipLaunchKernelGGL(k_pack_dense<PACK_SYM>, dgrid(ld), dblock, 0, h->stream, dC_inv, h->dCsym, N, ld, mask);
+        hipLaunchKernelGGL(k_pack_dense<PACK_COPY>, dgrid(ld), dblock, 0, h->stream, dM, h->dM, N, ld, mask);
+        hipLaunchKernelGGL(k_pack_dense<PACK_TRANS>, dgrid(ld), dblock, 0, h->stream, dM, h->dMt, N, ld, mask);
+        hipLaunchKernelGGL(k_pack_dense<PACK_SYM>, dgrid(ld), dblock, 0, h->stream, dK_inv, h->dKsym, N, ld, mask);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("pack launch: ") + hipGetErrorString(e));
 
@@ -180,9 +218,10 @@ int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double*
                *tKs = magi_workspace(h, magi_handle::WS_TKS, nn), *tE = magi_workspace(h, magi_handle::WS_TE, nn);
         if (!tCs || !tM || !tKs || !tE) return MAGI_E_HIP;
         dim3 gd((N + 255) / 256, N, D);
-        hipLaunchKernelGGL(k_pack<PACK_SYM>, gd, block, 0, h->stream, dC_inv, tCs, N, N, mask, 0);
-        hipLaunchKernelGGL(k_pack<PACK_COPY>, gd, block, 0, h->stream, dM, tM, N, N, mask, 0);
-        hipLaunchKernelGGL(k_pack<PACK_SYM>, gd, block, 0, h->stream, dK_inv, tKs, N, N, mask, 0);
+        (void)gd;
+        hipLaunchKernelGGL(k_pack_dense<PACK_SYM>, dgrid(N), dblock, 0, h->stream, dC_inv, tCs, N, N, mask);
+        hipLaunchKernelGGL(k_pack_dense<PACK_COPY>, dgrid(N), dblock, 0, h->stream, dM, tM, N, N, mask);
+        hipLaunchKernelGGL(k_pack_dense<PACK_SYM>, dgrid(N), dblock, 0, h->stream, dK_inv, tKs, N, N, mask);
         int rc = magi_fused_operators(h, N, D, tCs, tM, tKs, tE);
         if (rc == MAGI_OK) {
             hipLaunchKernelGGL(k_pack_tiles, dim3(n_tasks), dim3(256), 0, h->stream, tCs, tKs, tE, h->dTasks, h->dTiles, N, fb);
