@@ -18,7 +18,8 @@ After the headline region a one-GPU run (N = 1) also measures, untimed-setup sty
 BASELINE configs -- config 1 (SEIR-4, N = 161, b = 80, one chain, 200 + 200 NUTS steps, next to the torch-CPU leg),
 config 3's per-GPU share (8 chains, N = 1024), one dataset of config 4's alpha sweep (8 chains, N = 161, b = 80) and
 config 5 (N = 8192 x 4: one pooled build with per-class device times, and the streaming kernel on 4.4 GB of operator
-blocks) -- and reports them as FLAT scalars inside `roofline` (`cfg1_*`, `mc8_*`, `cfg4_*`, `n8192_*`).
+blocks) -- plus the hyper-parameter fit's ms per Adam step -- and reports them as FLAT scalars inside `roofline`
+(`cfg1_*`, `mc8_*`, `cfg4_*`, `n8192_*`, `f1_*`).
 """
 import argparse
 import json
@@ -473,6 +474,26 @@ def extra_configs(a, eng, host, MagiEngine, pb2, roofline, threads, dev_index):
                        "MAGI_BUILD_PROFILE=1 for the per-class device times (serialised: HIP events around every launch), then the streaming kernel "
                        "on the 4.4 GB of operator blocks (standalone, 20 launches: nothing is cache-resident at this size)")
     e5.close()
+
+    # ---- f1: GP hyper-parameter fit (magi_v2.py:538-691) -- ms per Adam step; the reference's only timing is this step at |I| ~ 2191 x 4:
+    #      about 9 s per iteration on its CPU host (output.log:23) ----
+    ef = MagiEngine(dev_index)
+    for Nf, iters in ((161, 100), (1024, 40), (2191, 20)):
+        If, Xf_obs, _, _ = host.synthetic_seir(Nf, seed=0)
+        Xf = host.linear_interpolate(Xf_obs)
+        pri = [host.fourier_phi2_prior(Xf[:, d]) for d in range(D)]
+        ini = host.hparams_initial(Xf)
+        args = (If, Xf, Xf.mean(axis=0), [p_[0] for p_ in pri], [p_[1] for p_ in pri], ini["sigma_sqs"], ini["phi1s"], ini["phi2s"], ini["sigma_sqs"])
+        ef.fit_hparams(*args, num_iters=3)                                                   # (allocations, graph capture)
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        fit = ef.fit_hparams(*args, num_iters=iters)
+        torch.cuda.synchronize()
+        roofline[f"f1_ms_per_adam_step_n{Nf}"] = round((time.perf_counter() - tf) / iters * 1e3, 4)
+        roofline[f"f1_finite_n{Nf}"] = bool(np.isfinite(fit["phi2s"]).all())
+    ef.close()
+    note["f1"] = ("GP hyper-parameter fit on the GPU (all 4 components; every Adam step = Matern assembly + Cholesky + inverse + trace terms), wall ms per step incl. "
+                  "the per-call set-up amortised over 100 / 40 / 20 steps; the reference logs ~9 s per step at |I| ~ 2191 (output.log:23)")
     return note
 
 

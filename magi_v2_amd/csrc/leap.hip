@@ -760,8 +760,11 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     // ---- the one round of loads in front of the tile stream: active bits, column slice(s) (block bj), this wave's row slice (block bi) ----
     // (the chains' active flags are LOADED here and balloted at the stores: a ballot in front of the operand loads made every workgroup
     //  wait 1.5 us for the plan's round trip before its first load -- device time stamps, tools/exp_sep_stamps.py)
+    //  -- and loaded LATE, two steps before the first store: held from the prologue on, the flag was the one register the streaming
+    //  body spilled)
     typedef const int __attribute__((address_space(1))) * gi_ptr;       // (a GLOBAL load: a flat one would also sit on the LDS counter)
-    const int act_flag = *(gi_ptr)(unsigned long long)&ch.plan[(size_t)(parity ^ 1) * nch + min(c0 + li, nch - 1)].active;
+    const gi_ptr act_ptr = (gi_ptr)(unsigned long long)&ch.plan[(size_t)(parity ^ 1) * nch + min(c0 + li, nch - 1)].active;
+    int act_flag = 0;
     const int groups = (nch + 15) >> 4;
     typedef const double __attribute__((address_space(1))) * gd_ptr;
     typedef const char __attribute__((address_space(1))) * gc_ptr;
@@ -825,6 +828,7 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     static_for<16>([&](auto S) {
         constexpr int s = decltype(S)::value;
         if (s < nsteps) {
+        if (s == 6) act_flag = *act_ptr;
         constexpr int sl = s & 7, cidx = sl & 1;
         const int g = (wave + (sl >> 1)) & 3;
         if (s == 8) {
