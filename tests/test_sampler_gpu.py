@@ -295,7 +295,8 @@ def test_checkpoint_resume_in_a_new_handle_continues_the_run_bit_for_bit(n_chain
         np.testing.assert_array_equal(getattr(dfull, f)[:, 7:], getattr(dpart, f)[:, 7:])
 
 
-@pytest.mark.parametrize("tag,chains", [("sirw_N41", 1), ("sirw_N41", 2), ("sirw_N41", 3), ("seir3_N161", 1), ("seir3_N161", 4), ("seir4_N81", 9)])
+@pytest.mark.parametrize("tag,chains", [("sirw_N41", 1), ("sirw_N41", 2), ("sirw_N41", 3), ("seir3_N161", 1), ("seir3_N161", 2), ("seir3_N161", 4),
+                                        ("seir4_N81", 1), ("seir4_N81", 2), ("seir4_N81", 9)])
 def test_deep_trees_match_oracle_draw_for_draw_in_every_kernel_family(tag, chains):
     """Every streaming-kernel instantiation a batch size selects (one chain: k_stream<1>, two: k_stream<2>, three or more: k_stream_sep
     with its basis planes -- SIRW has three basis functions per component, i.e. a second plane on grid.z; nine chains: the 16-wide
@@ -350,3 +351,33 @@ def test_fused_log_posterior_is_the_same_in_even_and_odd_slots(tag, monkeypatch)
         np.testing.assert_allclose(even[0], ref[0], rtol=1e-10)
         np.testing.assert_allclose(even[1], ref[1], rtol=0, atol=1e-10 * np.abs(ref[1]).max())
     eng.close()
+
+
+@pytest.mark.parametrize("tag,chains", [("sirw_N41", 1), ("sirw_N41", 2), ("sirw_N41", 4), ("seir4_N81", 1), ("seir4_N81", 2)])
+def test_fixed_length_hmc_first_transition_from_a_small_step_matches_oracle(tag, chains):
+    """ONE fixed-L HMC transition (L = 8) from a step of 1e-3: its log acceptance ratio is a scalar summary of the eight leapfrogs'
+    energies, and for SIRW the proposal is accepted (ratio 0).  This is the configuration in which round 3's one-chain SIRW kernel
+    rejected with log_accept_ratio -75.9 while every default-step test passed (tools/exp_family_hmc.py)."""
+    g = load_g4(tag)
+    pr = problem_from_g4(g, None)
+    eng = engine_for(pr, None)
+    X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], np.ones(pr.P), pr.LB)
+    L = 8
+    cfg = eng.default_cfg(num_results=1, num_burnin_steps=0, step_size=1e-3, mode=1, hmc_leapfrogs=L)
+    rep = lambda v: np.repeat(np.asarray(v)[None], chains, axis=0)
+    ids = list(range(7, 7 + chains))
+    eng.sampler_init(cfg, rep(X0), rep(s0), rep(t0), seed=31, chain_ids=ids)
+    eng.sampler_run(1)
+    Xs, sp, tp = eng.sampler_samples()
+    d = eng.sampler_diag()
+    eng.close()
+    for i in sorted({0, chains - 1}):
+        trace = []
+        oX, osp, otp, info, _ = orc.sample_chain(pr, g["Xhat_init"], g["sigma_sqs_init"], np.ones(pr.P), 1, 0, seed=31, chain=ids[i], step_size=1e-3,
+                                                 hmc_leapfrogs=L, trace=trace)
+        r = trace[0][1]
+        assert np.isfinite(r.log_accept_ratio) and (tag != "sirw_N41" or r.is_accepted)
+        assert int(d.is_accepted[i, 0]) == int(r.is_accepted)
+        np.testing.assert_allclose(d.log_accept_ratio[i, 0], r.log_accept_ratio, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(d.target_log_prob[i, 0], r.target_log_prob, rtol=1e-9)
+        np.testing.assert_allclose(tp[i], otp, rtol=1e-8, atol=1e-10)

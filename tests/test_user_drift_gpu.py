@@ -206,3 +206,36 @@ def test_user_drift_batched_states_on_the_matrix_core_kernel(name):
             np.testing.assert_allclose(out[1][c], gX, rtol=0, atol=1e-9 * np.abs(gX).max())
             np.testing.assert_allclose(out[3][c], gt, rtol=1e-8, atol=1e-9 * np.abs(gX).max())
     eng.close()
+
+
+@pytest.mark.parametrize("name,chains,theta0", [("fhn", 1, 1.0), ("fhn", 3, 1.0), ("lotka_volterra", 1, 1.0), ("lotka_volterra", 4, 1.0),
+                                                  ("ptrans", 1, 0.2), ("ptrans", 3, 0.2), ("competition7", 3, 1.0)])
+def test_traced_drift_deep_trees_match_oracle_in_every_kernel_family(name, chains, theta0):
+    """Every traced drift is its own library, i.e. its own instantiations of the streaming kernels and of the decisions inlined into
+    them: one chain (VALU kernel) and a batch (k_stream_sep for the separable FitzHugh-Nagumo -- three basis functions, two planes --,
+    Lotka-Volterra and the seven-parameter competition system; k_stream_mc for the protein-transduction system, whose V x / (K + x)
+    term is not separable) against the oracle on transitions that build trees (first step 2e-3: a rejected one-leapfrog transition,
+    what TFP's 0.1 produces early on, hides whatever the leapfrog computed)."""
+    eng, pr, Xhat, hp, truth = make_problem(name)
+    P = len(truth)
+    th0 = np.full(P, theta0)
+    sp0, tp0 = host.softplus_inverse_inits(hp["sigma_sqs"], th0, pr.LB)
+    burnin, results, step0, depth = 4, 2, 2e-3, 6
+    cfg = eng.default_cfg(num_results=results, num_burnin_steps=burnin, stale_cache=0, step_size=step0, max_tree_depth=depth)
+    rep = lambda v: np.repeat(np.asarray(v)[None], chains, axis=0)
+    ids = list(range(40, 40 + chains))
+    eng.sampler_init(cfg, rep(Xhat), rep(sp0), rep(tp0), seed=515, chain_ids=ids)
+    lf, _ = eng.sampler_run(burnin + results)
+    Xs, sp, tp = eng.sampler_samples()
+    d = eng.sampler_diag()
+    eng.close()
+    assert lf == d.leapfrogs_taken.sum() and d.leapfrogs_taken.max() >= 15 and d.is_accepted.sum() >= chains
+    for i in sorted({0, chains - 1}):
+        trace = []
+        oX, osp, otp, info, _ = orc.sample_chain(pr, Xhat, hp["sigma_sqs"], th0, results, burnin, seed=515, chain=ids[i], step_size=step0,
+                                                 stale_cache=False, trace=trace, max_tree_depth=depth)
+        np.testing.assert_array_equal(d.leapfrogs_taken[i], [r.leapfrogs for _, r, _ in trace])
+        np.testing.assert_array_equal(d.is_accepted[i], [int(r.is_accepted) for _, r, _ in trace])
+        np.testing.assert_allclose(d.target_log_prob[i], [r.target_log_prob for _, r, _ in trace], rtol=1e-8)
+        np.testing.assert_allclose(tp[i], otp, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(Xs[i], oX, rtol=0, atol=1e-8 * np.abs(oX).max())
