@@ -106,6 +106,7 @@ struct MaternArgs {
                                // fp64 arithmetic, so a small matrix wants one entry per thread rather than 16)
     const double* dyn;         // non-null: phi1, c, logA, diag_pp come from device memory (FitDyn below) -- the hyper-parameter
                                // fit replays one captured graph per Adam step, so its launch arguments cannot change
+    long bsK, bs_dyn;          // grid.z > 1 (the fit's batched step: all components in one launch): element strides of the outputs / dyn blocks
 };
 
 // 64 x 64 tile per 256-thread workgroup; the two 64-entry slices of the time grid staged in LDS
@@ -114,6 +115,11 @@ enum FitDyn { FD_RAW = 0, FD_M = 3, FD_V = 6, FD_PV = 9 /* phi1, phi2, sigma^2 *
 
 __global__ __launch_bounds__(256) void k_matern(MaternArgs a) {
     __shared__ double ts[64], tt[64];
+    if (gridDim.z > 1) {
+        const long z = blockIdx.z;
+        a.Kappa += z * a.bsK; a.pKappa += z * a.bsK; a.Kappapp += z * a.bsK;
+        if (a.dyn) a.dyn += z * a.bs_dyn;
+    }
     if (a.dyn) { a.phi1 = a.dyn[FD_PV]; a.c = a.dyn[FD_C]; a.logA = a.dyn[FD_LOGA]; a.diag_pp = a.dyn[FD_DIAGPP]; }
     const int i0 = blockIdx.y * a.rows, j0 = blockIdx.x * 64;
     if (threadIdx.x < 64) {
@@ -702,6 +708,8 @@ __global__ void k_symmetrize(double* A, int N) {             // A = (A + A^T)/2,
 __global__ void k_fit_shift(const double* __restrict__ Kap, double* __restrict__ S, int N, double shift, const double* __restrict__ dyn) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t)N * N) return;
+    Kap += (size_t)blockIdx.y * N * N; S += (size_t)blockIdx.y * N * N;          // (grid.y = component of a batched step)
+    if (dyn) dyn += (size_t)blockIdx.y * FD_COUNT;
     if (dyn) shift = dyn[FD_SHIFT];
     const int i = (int)(e / N), j = (int)(e - (size_t)i * N);
     S[e] = Kap[e] + (i == j ? shift : 0.0);
@@ -710,6 +718,7 @@ __global__ void k_fit_shift(const double* __restrict__ Kap, double* __restrict__
 // out[0] = sum_i log L_ii (one block)
 __global__ __launch_bounds__(256) void k_fit_logdiag(const double* __restrict__ L, int N, double* out) {
     __shared__ double sh[2 * 16];
+    L += (size_t)blockIdx.x * N * N; out += (size_t)blockIdx.x * 8;            // (grid.x = component; out blocks are 8 doubles apart)
     double v[1] = {0.0};
     for (int i = threadIdx.x; i < N; i += 256) v[0] += log(L[(size_t)i * N + i]);
     block_sum<1>(v, sh);
@@ -720,6 +729,7 @@ __global__ __launch_bounds__(256) void k_fit_logdiag(const double* __restrict__ 
 __global__ __launch_bounds__(256) void k_fit_gemv(const double* __restrict__ A, const double* __restrict__ r, double* __restrict__ y, int N) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= N) return;
+    A += (size_t)blockIdx.y * N * N; r += (size_t)blockIdx.y * N; y += (size_t)blockIdx.y * N;
     double s = 0.0;
     for (int j = lane; j < N; j += 64) s = fma(A[(size_t)row * N + j], r[j], s);
     s = wave_sum(s);
@@ -733,6 +743,10 @@ __global__ __launch_bounds__(256) void k_fit_terms(const double* __restrict__ Ka
                                                    int N, double* __restrict__ part /* [gridDim.x][5] */) {
     __shared__ double sh[6 * 16];
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    {   // grid.y = component (the time grid t is shared)
+        const size_t zn = (size_t)blockIdx.y * N, znn = zn * N;
+        Kap += znn; pK += znn; Sinv += znn; alpha += zn; r += zn; part += (size_t)blockIdx.y * gridDim.x * 5;
+    }
     double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     if (row < N) {
         const double ai = alpha[row], ti = t[row];
@@ -751,6 +765,7 @@ __global__ __launch_bounds__(256) void k_fit_terms(const double* __restrict__ Ka
 
 __global__ __launch_bounds__(256) void k_fit_final(const double* __restrict__ part, int nblk, double* out /* [5] */) {
     __shared__ double sh[6 * 16];
+    part += (size_t)blockIdx.x * nblk * 5; out += (size_t)blockIdx.x * 8;      // (grid.x = component)
     double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     for (int b = threadIdx.x; b < nblk; b += 256)
 #pragma unroll
@@ -770,6 +785,9 @@ struct FitStepArgs {
     double* trace;             // [iters]: D (loglik + log prior) of the parameters the step started from
     int N, D;
     double nu, lgam_nu, mu_phi2, sd_phi2, sig_loc, lr, jitter;
+    // batched step (grid.x = components; blocks of dyn / ist / out / status / trace are FD_COUNT / 4 / 8 / 2 / `iters` apart):
+    int batched, iters;
+    double mu_phi2_z[8], sd_phi2_z[8], sig_loc_z[8];
 };
 
 __device__ inline void fit_derive(double* dyn, double nu, double lgam_nu, double jitter) {
@@ -781,7 +799,12 @@ __device__ inline void fit_derive(double* dyn, double nu, double lgam_nu, double
 }
 
 __global__ void k_fit_step(FitStepArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    if (a.batched) {
+        const int z = blockIdx.x;
+        a.dyn += (size_t)z * FD_COUNT; a.ist += 4 * z; a.out += 8 * z; a.status += 2 * z; a.trace += (size_t)z * a.iters;
+        a.mu_phi2 = a.mu_phi2_z[z]; a.sd_phi2 = a.sd_phi2_z[z]; a.sig_loc = a.sig_loc_z[z];
+    } else if (blockIdx.x != 0) return;
     double* dyn = a.dyn;
     const int t = a.ist[0];
     if (t == 0) {                                      // first launch: hyper-parameters from the raw variables
@@ -1076,9 +1099,11 @@ BesselConsts bessel_consts(double nu) {
     return bc;
 }
 
-int launch_matern(magi_handle* h, const double* dI, int N, double phi1, double phi2, double nu, double* dK, double* dP, double* dPP, const double* dyn = nullptr) {
+int launch_matern(magi_handle* h, const double* dI, int N, double phi1, double phi2, double nu, double* dK, double* dP, double* dPP, const double* dyn = nullptr,
+                  int nz = 1) {
     MaternArgs a{};
     a.dyn = dyn;
+    a.bsK = (long)N * N; a.bs_dyn = FD_COUNT;      // (used when nz > 1: the batched fit step, hyper-parameters from the components' dyn blocks)
     a.I = dI; a.Kappa = dK; a.pKappa = dP; a.Kappapp = dPP; a.N = N;
     a.phi1 = phi1; a.nu = nu; a.c = std::sqrt(2.0 * nu) / phi2;
     a.logA = std::log(phi1) + (1.0 - nu) * std::log(2.0) - std::lgamma(nu);
@@ -1086,7 +1111,7 @@ int launch_matern(magi_handle* h, const double* dI, int N, double phi1, double p
     a.bc = bessel_consts(nu);
     a.rows = 64;
     while (a.rows > 4 && (long)((N + 63) / 64) * ((N + a.rows - 1) / a.rows) < 1024) a.rows /= 2;
-    dim3 grid((N + 63) / 64, (N + a.rows - 1) / a.rows);
+    dim3 grid((N + 63) / 64, (N + a.rows - 1) / a.rows, nz);
     prof_begin(h->stream);
     hipLaunchKernelGGL(k_matern, grid, dim3(256), 0, h->stream, a);
     prof_end(h->stream, BC_MATERN, 0.0);
@@ -1204,7 +1229,8 @@ int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const
             if (w.stream) (void)hipStreamDestroy(w.stream);
         }
     };
-    for (int d = 0; d < D && rc == MAGI_OK; ++d) {
+    const bool batched_fit = !getenv("MAGI_FIT_HOST_LOOP") && !getenv("MAGI_FIT_PER_COMPONENT") && D <= 8;
+    for (int d = 0; d < D && rc == MAGI_OK && !batched_fit; ++d) {
         FitWork& w = ws[d];
         w.N = N;
         w.nblk = (N + 3) / 4;
@@ -1231,6 +1257,105 @@ int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const
     // raw variables, order [phi1(D), phi2(D), sig2(D)] ; Adam state
     std::vector<double> raw(3 * D), m(3 * D, 0.0), v(3 * D, 0.0), grad(3 * D);
     for (int d = 0; d < D; ++d) { raw[d] = softplus_inv(phi1[d]); raw[D + d] = softplus_inv(phi2[d]); raw[2 * D + d] = softplus_inv(sig2[d]); }
+    if (batched_fit) {
+        // Round 3 -- ONE captured graph per Adam step for ALL components: the components go through the same launches, so every kernel of
+        // the step carries them on a grid axis (Matern blocks, shift, the batched Cholesky / inverse of the matrix build, the reductions,
+        // the scalar tail), their hyper-parameters in per-component FitDyn blocks FD_COUNT apart.  (Round 1 / 2: one graph per component
+        // on four streams that share two hardware queues -- MAGI_FIT_PER_COMPONENT=1 keeps that path for comparison.)
+        g_prof.on = false;
+        ws.clear();                                                   // (no per-component work spaces on this path)
+        DevBuf bI, br, bKap, bpK, bKpp, bS, bSinv, balpha, bpart, bout, bdyn, btrace;
+        int* ist = nullptr;
+        hipStream_t st = nullptr;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        Linalg la{};
+        const int nblk = (N + 3) / 4;
+        hipError_t e = hipSuccess;
+        auto chk = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+        chk(bI.alloc(N)); chk(br.alloc((size_t)D * N)); chk(bKap.alloc(nn * D)); chk(bpK.alloc(nn * D)); chk(bKpp.alloc(nn * D)); chk(bS.alloc(nn * D));
+        chk(bSinv.alloc(nn * D)); chk(balpha.alloc((size_t)D * N)); chk(bpart.alloc((size_t)D * nblk * 5)); chk(bout.alloc((size_t)D * 8));
+        chk(bdyn.alloc((size_t)D * FD_COUNT)); chk(btrace.alloc((size_t)D * std::max(iters, 1)));
+        chk(hipMalloc(reinterpret_cast<void**>(&ist), (size_t)D * 4 * sizeof(int)));
+        chk(hipStreamCreate(&st));
+        std::vector<double> rr((size_t)D * N), init((size_t)D * FD_COUNT, 0.0);
+        std::vector<int> ist0((size_t)D * 4, 0);
+        for (int d = 0; d < D; ++d) {
+            for (int i = 0; i < N; ++i) rr[(size_t)d * N + i] = X[(size_t)i * D + d] - mu[d];
+            for (int k = 0; k < 3; ++k) init[(size_t)d * FD_COUNT + FD_RAW + k] = raw[(size_t)k * D + d];
+            ist0[(size_t)d * 4 + 1] = -1;
+        }
+        if (e == hipSuccess) chk(hipMemcpy(bI.p, I, sizeof(double) * N, hipMemcpyHostToDevice));
+        if (e == hipSuccess) chk(hipMemcpy(br.p, rr.data(), sizeof(double) * rr.size(), hipMemcpyHostToDevice));
+        if (e == hipSuccess) chk(hipMemcpy(bdyn.p, init.data(), sizeof(double) * init.size(), hipMemcpyHostToDevice));
+        if (e == hipSuccess) chk(hipMemcpy(ist, ist0.data(), sizeof(int) * ist0.size(), hipMemcpyHostToDevice));
+        if (e == hipSuccess) chk(hipMemset(btrace.p, 0, (size_t)D * std::max(iters, 1) * sizeof(double)));
+        if (e != hipSuccess) rc = magi_fail(h, MAGI_E_HIP, std::string("fit setup: ") + hipGetErrorString(e));
+        if (rc == MAGI_OK) { rc = linalg_init(la, h, N, D, (long)nn); la.s = st; }
+        FitStepArgs sa{};
+        if (rc == MAGI_OK) {
+            sa.dyn = bdyn.p; sa.ist = ist; sa.out = bout.p; sa.status = la.status; sa.trace = btrace.p; sa.N = N; sa.D = D;
+            sa.nu = nu; sa.lgam_nu = std::lgamma(nu); sa.lr = lr; sa.jitter = jitter; sa.batched = 1; sa.iters = std::max(iters, 1);
+            for (int d = 0; d < D; ++d) { sa.mu_phi2_z[d] = mu_phi2[d]; sa.sd_phi2_z[d] = sd_phi2[d]; sa.sig_loc_z[d] = sig_loc[d]; }
+            hipLaunchKernelGGL(k_fit_step, dim3(D), dim3(64), 0, st, sa);             // t = 0: derive the first hyper-parameters
+            hipStream_t keep = h->stream;
+            h->stream = st;                                                           // (the helpers below launch on the handle's stream)
+            chk(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            if (e == hipSuccess) {
+                rc = launch_matern(h, bI.p, N, 1.0, 1.0, nu, bKap.p, bpK.p, bKpp.p, bdyn.p, D);
+                if (rc == MAGI_OK) {
+                    hipLaunchKernelGGL(k_fit_shift, dim3((unsigned)((nn + 255) / 256), D), dim3(256), 0, st, bKap.p, bS.p, N, 1.0, bdyn.p);
+                    rc = potrf(la, bS.p, "GP marginal covariance", true);
+                }
+                if (rc == MAGI_OK) {
+                    hipLaunchKernelGGL(k_fit_logdiag, dim3(D), dim3(256), 0, st, bS.p, N, bout.p + 5);
+                    rc = trtri(la, bS.p);
+                }
+                if (rc == MAGI_OK) rc = lauum_tt(la, bS.p, bSinv.p, (long)nn);
+                if (rc == MAGI_OK) {
+                    hipLaunchKernelGGL(k_fit_gemv, dim3((N + 3) / 4, D), dim3(256), 0, st, bSinv.p, br.p, balpha.p, N);
+                    hipLaunchKernelGGL(k_fit_terms, dim3(nblk, D), dim3(256), 0, st, bKap.p, bpK.p, bSinv.p, balpha.p, br.p, bI.p, N, bpart.p);
+                    hipLaunchKernelGGL(k_fit_final, dim3(D), dim3(256), 0, st, bpart.p, nblk, bout.p);
+                    hipLaunchKernelGGL(k_fit_step, dim3(D), dim3(64), 0, st, sa);
+                }
+                chk(hipStreamEndCapture(st, &graph));
+            }
+            h->stream = keep;
+            if (e == hipSuccess && rc == MAGI_OK) chk(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            if (e != hipSuccess && rc == MAGI_OK) rc = magi_fail(h, MAGI_E_HIP, std::string("fit graph: ") + hipGetErrorString(e));
+        }
+        for (int t = 1; t <= iters && rc == MAGI_OK; ++t)
+            if (hipGraphLaunch(exec, st) != hipSuccess) rc = magi_fail(h, MAGI_E_HIP, "fit graph launch");
+        std::vector<double> tr((size_t)std::max(iters, 1) * D, 0.0), fin((size_t)D * FD_COUNT, 0.0);
+        std::vector<int> istv((size_t)D * 4, 0);
+        if (st) (void)hipStreamSynchronize(st);
+        if (rc == MAGI_OK) {
+            hipError_t e2 = hipMemcpy(fin.data(), bdyn.p, sizeof(double) * fin.size(), hipMemcpyDeviceToHost);
+            if (e2 == hipSuccess) e2 = hipMemcpy(istv.data(), ist, sizeof(int) * istv.size(), hipMemcpyDeviceToHost);
+            if (e2 == hipSuccess && iters > 0) e2 = hipMemcpy(tr.data(), btrace.p, (size_t)iters * D * sizeof(double), hipMemcpyDeviceToHost);
+            if (e2 != hipSuccess) rc = magi_fail(h, MAGI_E_HIP, std::string("fit: ") + hipGetErrorString(e2));
+        }
+        for (int d = 0; d < D && rc == MAGI_OK; ++d) {
+            if (istv[(size_t)d * 4 + 1] >= 0)
+                rc = magi_fail(h, MAGI_E_NOTSPD, "Cholesky of GP marginal covariance (component " + std::to_string(d) + ", Adam step " + std::to_string(istv[(size_t)d * 4 + 2]) +
+                               "): non-positive pivot at index " + std::to_string(istv[(size_t)d * 4 + 1]));
+            for (int k = 0; k < 3; ++k) raw[(size_t)k * D + d] = fin[(size_t)d * FD_COUNT + FD_RAW + k];
+        }
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        linalg_free(la);
+        if (ist) (void)hipFree(ist);
+        if (st) (void)hipStreamDestroy(st);
+        if (rc) return rc;
+        if (loss_trace)
+            for (int t = 0; t < iters; ++t) {
+                double loss = 0.0;
+                for (int d = 0; d < D; ++d) loss -= tr[(size_t)d * iters + t];
+                loss_trace[t] = loss;
+            }
+        for (int d = 0; d < D; ++d) { phi1[d] = softplus(raw[d]); phi2[d] = softplus(raw[D + d]); sig2[d] = softplus(raw[2 * D + d]); }
+        return MAGI_OK;
+    }
     if (!getenv("MAGI_FIT_HOST_LOOP")) {
         // Device-resident loop: one Adam step of one component = one captured graph (Matern blocks -> Cholesky -> inverse ->
         // reductions -> k_fit_step) whose inputs live in the component's FitDyn block; the host replays it `iters` times on

@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, ".")
 from magi_v2_amd import host
 from magi_v2_amd.engine import MagiEngine
-for N, iters in ((161, 400), (1024, 40)):
+for N, iters in ((161, 400), (1024, 40), (2191, 10)):
     I, X_obs, truth, th = host.synthetic_seir(N, seed=0)
     Xi = host.linear_interpolate(X_obs)
     pri = [host.fourier_phi2_prior(Xi[:, d]) for d in range(4)]
