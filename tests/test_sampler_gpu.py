@@ -295,17 +295,18 @@ def test_checkpoint_resume_in_a_new_handle_continues_the_run_bit_for_bit(n_chain
         np.testing.assert_array_equal(getattr(dfull, f)[:, 7:], getattr(dpart, f)[:, 7:])
 
 
-@pytest.mark.parametrize("tag,chains", [("sirw_N41", 1), ("sirw_N41", 2), ("sirw_N41", 3), ("seir3_N161", 1), ("seir3_N161", 2), ("seir3_N161", 4),
-                                        ("seir4_N81", 1), ("seir4_N81", 2), ("seir4_N81", 9)])
-def test_deep_trees_match_oracle_draw_for_draw_in_every_kernel_family(tag, chains):
+@pytest.mark.parametrize("tag,chains,band", [("sirw_N41", 1, None), ("sirw_N41", 2, None), ("sirw_N41", 3, None), ("seir3_N161", 1, None), ("seir3_N161", 2, None),
+                                             ("seir3_N161", 4, None), ("seir4_N81", 1, None), ("seir4_N81", 2, None), ("seir4_N81", 9, None),
+                                             ("seir3_N161", 1, 20), ("seir3_N161", 4, 20), ("seir3_N161", 5, 80), ("sirw_N41", 3, 5)])
+def test_deep_trees_match_oracle_draw_for_draw_in_every_kernel_family(tag, chains, band):
     """Every streaming-kernel instantiation a batch size selects (one chain: k_stream<1>, two: k_stream<2>, three or more: k_stream_sep
     with its basis planes -- SIRW has three basis functions per component, i.e. a second plane on grid.z; nine chains: the 16-wide
     mirror) against the oracle on transitions that BUILD trees: a first step size of 2e-3 gives trees of depth 5-9 from the first
     transition on, where the reference's 0.1 makes the early transitions reject after one leapfrog -- and a rejected transition
     hides whatever its leapfrogs computed (round 3: a one-chain SIRW build with wrong energies passed every default-step test)."""
     g = load_g4(tag)
-    pr = problem_from_g4(g, None)
-    eng = engine_for(pr, None)
+    pr = problem_from_g4(g, band)                       # (band: the reference's band_part mask; b = 20 at N = 161 keeps only the blocks that meet the 3b-wide band)
+    eng = engine_for(problem_from_g4(g, None), band)
     X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], np.ones(pr.P), pr.LB)
     burnin, results, step0, depth = 4, 3, 2e-3, 7
     cfg = eng.default_cfg(num_results=results, num_burnin_steps=burnin, step_size=step0, max_tree_depth=depth, stale_cache=0)
