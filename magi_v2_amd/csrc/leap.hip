@@ -650,8 +650,8 @@ void k_stream_mc(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
 // sums of the slot before.  Prologue = ONE round of loads (operand slices, the chains' active bits), no transcendental.
 // The 16 matrix-core columns of a pass are (basis function k, chain): up to 8 chains x 2 basis functions (CW = 8) or 16 chains x 1
 // (CW = 16); further basis planes are served by further workgroups on grid.z (they re-read the tile: rare shapes only).
-// Work per workgroup is EQUAL: the kernel is bound by the fp64 matrix pipe (measured 47-50 ns per v_mfma_f64_16x16x4_f64 and SIMD when
-// two or three waves keep it busy, tools/micro/mfma_rate.hip: 44 TFLOP/s, not the 78.6 of the data sheet), a diagonal block of FH / FK
+// Work per workgroup is EQUAL: a workgroup's time is its stream of tile bytes with the MFMAs hidden under it (30-31 ns per
+// v_mfma_f64_16x16x4_f64 and SIMD, tools/micro/mfma_rate.hip: 7.7 us of matrix pipe at two workgroups per CU), a diagonal block of FH / FK
 // has only the row-type product (half the MFMAs), and 544 blocks put a third workgroup on 32 of the 256 CUs -- so the task table
 // (pack.hip: stasks) pairs the two diagonal blocks FH_bb, FK_bb of a component into ONE task of 16 row-type steps: dense N = 1024,
 // D = 4: 480 + 32 = 512 tasks of 128 MFMAs per wave, two per CU.

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 using d4 = __attribute__((ext_vector_type(4))) double;
+// The MFMA is issued through inline assembly with the accumulator tied to its own registers: with the builtin in a loop the compiler
+// (ROCm 7.2) keeps the loop-carried accumulators in VGPRs, the MFMA's in AGPRs, and copies all of them both ways in every iteration
+// (v_accvgpr_write / _read + s_nop) -- the first version of this file measured those copies (47-50 ns per MFMA, "44 TFLOP/s").
 template <int CHAINS>
 __global__ __launch_bounds__(256) void k(double* out, int iters) {
     d4 acc[CHAINS];
@@ -10,8 +13,9 @@ __global__ __launch_bounds__(256) void k(double* out, int iters) {
     double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
-        for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+        for (int c = 0; c < CHAINS; ++c) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[c]) : "v"(a), "v"(b));
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // (the results are read by VALU code the compiler schedules without knowing of the MFMAs)
     double s = 0.0;
     for (int c = 0; c < CHAINS; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
     if (s == 12345.678) out[0] = s;
