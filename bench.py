@@ -375,7 +375,7 @@ def extra_configs(a, eng, host, MagiEngine, pb2, roofline, threads, dev_index):
     rep8 = lambda v: np.repeat(np.asarray(v)[None], 8, axis=0)
 
     # ---- config 3's per-GPU share: 8 independent chains at N = 1024 (global ids 0..7 = rank 0 of 8) ----
-    steps3 = 50
+    steps3 = 200                        # (the chains of a run end at different times and the run ends with the slowest: 29 % of the chain-slots idle over 50 transitions, 16 % over 200)
     cfg3 = eng.default_cfg(num_results=steps3 + 3 + 8, num_burnin_steps=a.burnin, stale_cache=0)
     el, lf3, dev_ms, slots = timed_run(eng, cfg3, pb2, 8, list(range(8)), a.seed, a.burnin, 3, steps3)
     st_us, pt_us, _ = eng.sampler_profile(a.profile_slots)
