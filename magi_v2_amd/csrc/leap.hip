@@ -664,7 +664,10 @@ template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 #ifndef MAGI_SEP_RING
-#define MAGI_SEP_RING 2      // steps of tile loads per wave in the ring (2: 19.2 us, 3: 20.6, 4: 22.6 at 8 chains -- the kernel is bound by the fp64 matrix pipe, and a deeper ring only delays the first MFMA)
+#define MAGI_SEP_RING 2      // steps of tile loads per wave in the ring.  8 chains, standalone: 2: 18.7-19.0 us; 3: 24.6 and 4: 30.7 as the code stands --
+                             // at 168 registers the deeper rings SPILL inside the streaming body; 3 without spills (the pair's second operand slice
+                             // loaded at step 5 instead of the prologue): 19.8, with the operand loads in front of the ring 20.3.  More bytes in
+                             // flight per wave do not help this memory system (k_stream: 12.0 / 12.1 / 12.7 / 14.6 us for 1 / 2 / 3 / 4 row chunks).
 #endif
 constexpr int SEP_RING = MAGI_SEP_RING;
 #ifndef MAGI_SEP_OCC
