@@ -113,11 +113,10 @@ __device__ __forceinline__ LeafPlan make_leaf_plan(const ChainCtl& c, unsigned l
 
 // All threads of a 256-thread workgroup call it; `parity` = slot whose stream is running next to these decisions
 // (they complete slot parity ^ 1 ... i.e. the slot the point phase executed last, and write plan[parity]).
-// SEPK: the kernel these decisions ride in is k_stream_sep (they then also write the operand mirror of a state they set up).  A template
-// parameter, not a test of ch.sep: with the mirror pass merely COMPILED into the VALU kernels (never executed there) the one-chain SIRW
-// instantiation sampled wrong energies (tools/exp_family_hmc.py; round 3) -- the decision path is at the edge of what the register
-// allocator handles, and every instantiation is therefore held to an oracle run with deep trees (tests/test_sampler_gpu.py).
-template <int DRIFT, bool SEPK = false>
+// (Round 3 found this path at the edge of what the register allocator handles: with a pass for another kernel family merely COMPILED into the
+// one-chain SIRW instantiation -- never executed -- it sampled wrong energies (tools/exp_family_hmc.py).  Every instantiation is therefore held
+// to an oracle run with deep trees, tests/test_sampler_gpu.py; the state-sized passes have since moved to the point kernel, boundary_block.)
+template <int DRIFT>
 __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChains& ch, const SamplerCfgDev& cfg, int chain, int parity, int all_done,
                                              double* sh /* 25*16 */, double* shs /* 24 */, ChainCtl* s_ctl, int* s_g, double* s_par /* PAR_COUNT */, double* s_ops /* OPS_COUNT * OPS_W */, double* s_cst /* 3 * MAGI_MAX_D: N_ds, LB, mu */) {
     const int tid = threadIdx.x;
@@ -164,35 +163,51 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
     const TailVecs v = tail_vecs(pb, vb);
     const size_t sv = pb.dimp;
 
-    bool do_sample = false, do_doubling = false;     // what to set up before returning
     const bool hmc = cfg.mode == MAGI_MODE_HMC;       // fixed-L HMC: one forward "subtree" of L leaves, Metropolis at its end
+    // What this pass orders from the slot's point phase (boundary_block, leap_point.h): every state-sized pass of a subtree's or a
+    // transition's end is element by element and runs there, on all workgroups of the point kernel -- here it was a loop of dependent
+    // round trips on ONE workgroup next to the saturating stream (25-100 us per pass while every chain's slot waited for the kernel to
+    // end; round 2 spread the passes of chain batches over extra slots).  These decisions keep the scalars.
+    int vop = 0;
+    bool finish = false;          // transition c.k ends with this pass
+    bool start = false;           // a transition starts (temperature, momentum draw, first doubling)
+    bool doubling = false;        // a doubling starts
+    bool continue_tree = false;
+    int vleaf = lp.cur, vdir = 0;
 
-    if (lp.active && lp.skip) {
-        // the state set up by the previous decisions is only now being evaluated by the stream next to us: publish
-        // what the point phase has to do with it
-        if (tid == 0) {
-            LeafPlan p{};
-            if (c.phase == PH_LEAF) p = make_leaf_plan(c, cfg.seed, hmc);
-            else if (c.phase == PH_INIT) { p.active = 1; p.cur = c.cur; }       // bootstrap gradient, no leapfrog
-            *plan_out = p;
+    if (lp.vop != 0 && (c.phase == PH_DRAWN || c.phase == PH_MERGED)) {
+        // ---- sums of the boundary op the point phase has just executed (fixed order: lane = workgroup, butterfly) ----
+        constexpr int K0 = RedLayout<DRIFT>::K0;
+        {
+            const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+            for (int i = 0; i < RedLayout<DRIFT>::PER_WAVE; ++i) {
+                const int k = wave + RED_WAVES * i;
+                const double vsum = wave_sum(pre[i]);
+                if (lane == 0 && k < K0 + 8) sh[k] = vsum;
+            }
+            __syncthreads();
         }
-        return;
-    }
-    // Batches of NUTS chains (three or more per GPU): a subtree end (merge pass, then the set-up pass of the next doubling) or a
-    // transition end (merge, sample, momentum draw, set-up) keeps ONE workgroup busy for 25-100 us while every other chain's slot
-    // waits for the kernel to end -- with eight chains a quarter of the slots carried such a tail (k_stream_mc 26.2 us in the sampler
-    // against 22.7 us by itself).  There the passes go into consecutive slots, each short enough to hide under the stream: the chain
-    // publishes an idle plan in between (its point phase and the stream's output for it are off), at the price of one or two more
-    // set-up slots per subtree for that chain.  Fixed-L HMC chains end their transitions in step: nothing to gain, left alone.
-    const bool spread = !hmc && ch.n_chains >= 3;
-    const int phase_in = c.phase;
-    if (c.phase == PH_PEND_DOUBLE) {
-        do_doubling = true;
-    } else if (c.phase == PH_PEND_SAMPLE) {
-        do_sample = true;
+        const double pp0 = sh[K0 - 1], dot0 = sh[K0], dot1 = sh[K0 + 1];
+        if (c.phase == PH_DRAWN) {
+            // the momentum of transition c.k is drawn and its first state set up (the stream next to us is evaluating it)
+            c.init_energy = c.cand_bfac * c.cand_L - 0.5 * pp0;
+            c.cand_energy = c.init_energy;
+            c.phase = PH_LEAF;
+            if (tid == 0) { *plan_out = make_leaf_plan(c, cfg.seed, hmc); ch.ctl[chain] = c; }
+            return;
+        }
+        // PH_MERGED: the subtree is merged; does the trajectory go on?
+        continue_tree = (dot0 > 0.0) && (dot1 > 0.0);          // (c.cont != 0 and not HMC, or this phase would not have been entered)
+        if (continue_tree && c.depth < cfg.max_depth) {
+            c.phase = PH_LEAF;                                   // the doubling set up speculatively with the merge stands
+            if (tid == 0) { *plan_out = make_leaf_plan(c, cfg.seed, hmc); ch.ctl[chain] = c; }
+            return;
+        }
+        finish = true;                                           // (the proposal was merged with the subtree: nothing of VOP_CAND left)
     } else if (c.phase == PH_IDLE) {
         if (c.k < stop_k) {
-            do_sample = true;                        // resumed by a later magi_sampler_run
+            start = true;                            // resumed by a later magi_sampler_run
         } else {
             if (tid == 0) { LeafPlan off{}; *plan_out = off; }       // (both ring entries must read "idle")
             if (c.done_epoch != epoch) {
@@ -205,6 +220,15 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
             }
             return;
         }
+    } else if (lp.active && lp.skip) {
+        // (slot 0 of a fresh sampler: the stream next to us evaluates the initial state, the point phase gets the bootstrap plan)
+        if (tid == 0) {
+            LeafPlan p{};
+            if (c.phase == PH_LEAF) p = make_leaf_plan(c, cfg.seed, hmc);
+            else if (c.phase == PH_INIT) { p.active = 1; p.cur = c.cur; }       // bootstrap gradient, no leapfrog
+            *plan_out = p;
+        }
+        return;
     } else {
         const bool leaf = lp.leaf != 0;
         MAGI_STAMP(par, 1);
@@ -221,11 +245,11 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
         double* pleaf = vb + (size_t)V_PLEAF * sv;
 
         if (!leaf) {
-            // bootstrap_results: target / gradient at the initial state, cached at beta_temp(0)
-            copy2_batched(v.candq, qcur, v.candg, v.g, dim);
+            // bootstrap_results: target / gradient at the initial state, cached at beta_temp(0); the proposal <- the initial state
+            vop |= VOP_CAND | VOP_TAKE_LEAF;
             c.cand_L = L;
             c.beta_cache = shs[16];
-            if (c.k < stop_k) do_sample = true;
+            if (c.k < stop_k) start = true;
             else c.phase = PH_IDLE;
         } else {
             c.L_cur = L;
@@ -303,151 +327,76 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
             // ---- subtree finished: merge into the trajectory (biased progressive sampling); for HMC the
             //      "subtree" is the whole trajectory and the merge is the Metropolis test on its last state ----
             const double tree_weight = c.cont ? c.sub_weight : -INFINITY;
-            if (tid == 0) shs[20] = hmc ? 0.0 : logaddexp(tree_weight, c.cand_weight);
+            const double new_weight = hmc ? 0.0 : logaddexp(tree_weight, c.cand_weight);
             const double thresh = hmc ? ediff : tree_weight - c.cand_weight;
             const bool choose = (u_merge <= thresh) && (hmc ? not_divergent : (c.cont != 0));
-            double* pe = (c.dir > 0) ? v.pR : v.pL;
-            double* qe = (c.dir > 0) ? v.qR : v.qL;
-            double* ge = (c.dir > 0) ? v.gR : v.gL;
-            const double* po_ = (c.dir > 0) ? v.pL : v.pR;    // the other end
-            double dots[2] = {0.0, 0.0};
-            const bool take_leaf = accept_leaf || hmc;
-            constexpr int DBM = 4;
-            for (int e0 = tid; e0 < dim; e0 += DBM * (int)blockDim.x) {       // DBM elements' loads in flight, then their stores
-                double qv[DBM], gv[DBM], sq[DBM], sg[DBM], pn[DBM], rr[DBM], po[DBM];
-#pragma unroll
-                for (int u = 0; u < DBM; ++u) {
-                    const int e = e0 + u * (int)blockDim.x;
-                    if (e < dim) {
-                        qv[u] = qcur[e]; gv[u] = v.g[e];
-                        // the subtree proposal is this leaf if it was just accepted, else what V_SUB holds
-                        sq[u] = take_leaf ? qv[u] : v.subq[e]; sg[u] = take_leaf ? gv[u] : v.subg[e];
-                        pn[u] = pleaf[e];
-                        rr[u] = v.rho[e] + v.rhosub[e];
-                        po[u] = po_[e];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < DBM; ++u) {
-                    const int e = e0 + u * (int)blockDim.x;
-                    if (e < dim) {
-                        if (choose) { v.candq[e] = sq[u]; v.candg[e] = sg[u]; }
-                        pe[e] = pn[u]; qe[e] = qv[u]; ge[e] = gv[u];
-                        v.rho[e] = rr[u];
-                        dots[0] = fma(rr[u], po[u], dots[0]);
-                        dots[1] = fma(rr[u], pn[u], dots[1]);
-                    }
-                }
-            }
-            block_sum<2>(dots, sh);        // (its barriers publish shs[20])
+            const bool take_leaf = accept_leaf || hmc;         // the subtree proposal is this leaf if it was just accepted, else what V_SUB holds
+            if (choose) vop |= VOP_CAND | (take_leaf ? VOP_TAKE_LEAF : 0);
             if (hmc) { c.sub_L = L; c.sub_energy = energy; }
             if (choose) { c.cand_L = c.sub_L; c.cand_energy = c.sub_energy; c.cand_bfac = c.beta_k; c.is_accepted = 1; }
-            c.cand_weight = shs[20];
+            c.cand_weight = new_weight;
             if (c.dir > 0) { c.LR = c.L_cur; c.bfacR = c.beta_k; } else { c.LL = c.L_cur; c.bfacL = c.beta_k; }
-            const bool no_u_traj = (dots[0] > 0.0) && (dots[1] > 0.0);
             c.e_sum += c.e_sum_sub;
             c.lf_count += c.sub_lf;
             c.not_div = c.nd;
             c.depth += 1;
-            const bool continue_tree = !hmc && (c.cont != 0) && no_u_traj;
             if (hmc) { c.e_sum = shs[19]; }          // acceptance statistic of HMC: min(1, exp(energy difference))
-            if (c.depth < cfg.max_depth && continue_tree) {
-                if (spread) {
-                    c.phase = PH_PEND_DOUBLE;
-                    if (tid == 0) { LeafPlan off{}; *plan_out = off; ch.ctl[chain] = c; }
-                    return;
-                }
-                do_doubling = true;
+            if (hmc || c.cont == 0) {
+                finish = true;                         // (a rejected subtree ends the transition whatever the trajectory-level U-turn test says)
             } else {
-                // ---- transition finished ------------------------------------------------------------------
-                if (tid == 0)
-                    dual_averaging_eval(cfg.target_accept, cfg.n_adapt, c.da_step, c.da_step_size, c.da_error_sum, c.da_log_avg,
-                                        c.da_log_shrink, c.e_sum, hmc ? 1 : c.lf_count, &shs[0]);
-                __syncthreads();
-                const int k = c.k;
-                if (tid == 0) {
-                    const size_t o = (size_t)chain * cfg.total + k;
-                    ch.d_step_size[o] = c.eps;
-                    ch.d_lar[o] = shs[0];
-                    ch.d_target[o] = c.cand_bfac * c.cand_L;
-                    ch.d_energy[o] = c.cand_energy;
-                    ch.d_beta[o] = c.beta_k;
-                    ch.d_leapfrogs[o] = c.lf_count;
-                    ch.d_depth[o] = c.depth;
-                    ch.d_flags[o] = (c.not_div ? 0 : 1) | (continue_tree ? 2 : 0) | (c.is_accepted ? 4 : 0);
-                }
-                if (k >= cfg.burnin) {
-                    double* out = ch.samples + ((size_t)chain * (cfg.total - cfg.burnin) + (k - cfg.burnin)) * pb.dimp;
-                    copy2_batched(out, v.candq, nullptr, nullptr, dim);
-                }
-                if (c.is_accepted) c.beta_cache = c.beta_k;
-                c.da_step_size = shs[1];
-                c.da_error_sum = shs[2];
-                c.da_log_avg = shs[3];
-                c.da_step += 1;
-                c.k = k + 1;
-                if (c.k >= stop_k) {
-                    c.phase = PH_IDLE;
-                    c.done_epoch = epoch;
-                    if (tid == 0) {
-                        LeafPlan off{};
-                        *plan_out = off;
-                        ch.ctl[chain] = c;
-                        const int done = atomicAdd(&ch.gctl->done_chains, 1) + 1;
-                        if (done >= ch.gctl->n_chains) ch.gctl->all_done = 1;
-                    }
-                    return;
-                }
-                if (spread) {
-                    c.phase = PH_PEND_SAMPLE;
-                    if (tid == 0) { LeafPlan off{}; *plan_out = off; ch.ctl[chain] = c; }
-                    return;
-                }
-                do_sample = true;
+                // the trajectory-level U-turn test needs rho . p over the merged state: the point phase merges (ends, rho, proposal) and
+                // leaves the two sums; the next doubling is set up with it, speculatively (the stream of the next slot evaluates its first
+                // state; if the sums say "stop", that evaluation is dropped and the transition ends one slot later)
+                vop |= VOP_ENDS;
+                vdir = c.dir;
+                c.phase = PH_MERGED;
+                if (c.depth < cfg.max_depth) doubling = true;
             }
         }
     }
 
-    if (do_sample) {
-        // ---- start transition k: temperature, momentum draw, both ends = current proposal ----------------
+    if (finish) {
+        // ---- transition finished ------------------------------------------------------------------
+        __syncthreads();
+        if (tid == 0)
+            dual_averaging_eval(cfg.target_accept, cfg.n_adapt, c.da_step, c.da_step_size, c.da_error_sum, c.da_log_avg,
+                                c.da_log_shrink, c.e_sum, hmc ? 1 : c.lf_count, &shs[0]);
+        __syncthreads();
+        const int k = c.k;
+        if (tid == 0) {
+            const size_t o = (size_t)chain * cfg.total + k;
+            ch.d_step_size[o] = c.eps;
+            ch.d_lar[o] = shs[0];
+            ch.d_target[o] = c.cand_bfac * c.cand_L;
+            ch.d_energy[o] = c.cand_energy;
+            ch.d_beta[o] = c.beta_k;
+            ch.d_leapfrogs[o] = c.lf_count;
+            ch.d_depth[o] = c.depth;
+            ch.d_flags[o] = (c.not_div ? 0 : 1) | (continue_tree ? 2 : 0) | (c.is_accepted ? 4 : 0);
+        }
+        if (k >= cfg.burnin) vop |= VOP_OUT;
+        if (c.is_accepted) c.beta_cache = c.beta_k;
+        c.da_step_size = shs[1];
+        c.da_error_sum = shs[2];
+        c.da_log_avg = shs[3];
+        c.da_step += 1;
+        c.k = k + 1;
+        if (c.k >= stop_k) c.phase = PH_IDLE;        // (reported idle by the next slot's decisions: this slot's point phase still has the op below to run)
+        else start = true;
+    }
+    const long long vout = (long long)chain * (cfg.total - cfg.burnin) + (c.k - 1 - cfg.burnin);      // (used with VOP_OUT only: c.k was just advanced)
+
+    if (start) {
+        // ---- start transition c.k: temperature, momentum draw (point phase), both ends = current proposal ----------------
         __syncthreads();
         if (tid == 0) shs[4] = cfg.anneal ? temperature(c.k, cfg.min_temp) : 1.0;
-        double pp0[1] = {0.0};
-        // (pair j = elements 2 j, 2 j + 1 of the state: one Philox block, one log / sqrt per pair; 16-B accesses -- every vector is
-        //  16-B aligned and padded to an even length)
-        constexpr int DBP = 4;
-        const int npair = (dim + 1) >> 1;
-        for (int j0 = tid; j0 < npair; j0 += DBP * (int)blockDim.x) {
-            double2 qq[DBP], gg[DBP];
-#pragma unroll
-            for (int u = 0; u < DBP; ++u) {
-                const int j = j0 + u * (int)blockDim.x;
-                if (j < npair) { qq[u] = reinterpret_cast<const double2*>(v.candq)[j]; gg[u] = reinterpret_cast<const double2*>(v.candg)[j]; }
-            }
-#pragma unroll
-            for (int u = 0; u < DBP; ++u) {
-                const int j = j0 + u * (int)blockDim.x;
-                if (j < npair) {
-                    double2 z;
-                    rng_normal_pair((unsigned)j, (unsigned)c.k, (unsigned)c.chain_id, cfg.seed, z.x, z.y);
-                    if (2 * j + 1 >= dim) z.y = 0.0;                 // (odd dim: the pad entry stays zero)
-                    pp0[0] = fma(z.x, z.x, pp0[0]);
-                    pp0[0] = fma(z.y, z.y, pp0[0]);
-                    reinterpret_cast<double2*>(v.pL)[j] = z; reinterpret_cast<double2*>(v.pR)[j] = z; reinterpret_cast<double2*>(v.rho)[j] = z;
-                    reinterpret_cast<double2*>(v.qL)[j] = qq[u]; reinterpret_cast<double2*>(v.qR)[j] = qq[u];
-                    reinterpret_cast<double2*>(v.gL)[j] = gg[u]; reinterpret_cast<double2*>(v.gR)[j] = gg[u];
-                }
-            }
-        }
-        block_sum<1>(pp0, sh);              // (its barriers also publish shs[4])
+        __syncthreads();
         c.beta_k = shs[4];
         const double bc = cfg.stale ? c.beta_cache : c.beta_k;
         c.eps = c.da_step_size;
-        c.init_energy = bc * c.cand_L - 0.5 * pp0[0];
         c.LL = c.LR = c.cand_L;
         c.bfacL = c.bfacR = bc;
-        c.cand_bfac = bc;
-        c.cand_energy = c.init_energy;
+        c.cand_bfac = bc;                 // (init_energy = bc cand_L - p.p / 2 follows with the draw's sum: PH_DRAWN)
         c.cand_weight = 0.0;
         c.e_sum = 0.0;
         c.lf_count = 0;
@@ -455,77 +404,20 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
         c.is_accepted = 0;
         c.depth = 0;
         c.leaf_ctr = 0;
-        if (spread && phase_in == PH_PEND_SAMPLE) {
-            c.phase = PH_PEND_DOUBLE;
-            if (tid == 0) { LeafPlan off{}; *plan_out = off; ch.ctl[chain] = c; }
-            return;
-        }
-        do_doubling = true;
+        vop |= VOP_DRAW;
+        doubling = true;
     }
 
-    if (do_doubling) {
-        // ---- start a doubling from the end selected by the direction bit; first half/full step ----------
-        // (leapfrog with identity mass: p_half = p + eps/2 * grad ; q' = q + eps * p_half)
+    double d_eps = 0.0, d_hs = 0.0;
+    if (doubling) {
+        // ---- a doubling from the end selected by the direction bit: the point phase takes the first half / full step ----------
         Philox4 r = philox4x32_10((unsigned)c.depth, (unsigned)c.k, (unsigned)c.chain_id, STREAM_DIRECTION, cfg.seed);
         const bool fwd = hmc || (r.x & 1u) != 0;
         c.dir = fwd ? 1 : -1;
-        const double* pe = fwd ? v.pR : v.pL;
-        const double* qe = fwd ? v.qR : v.qL;
-        const double* ge = fwd ? v.gR : v.gL;
         const double bf = fwd ? c.bfacR : c.bfacL;
-        const double eps = c.dir * c.eps;
-        const double hs = 0.5 * eps * bf;
+        d_eps = c.dir * c.eps;
+        d_hs = 0.5 * d_eps * bf;
         c.cur ^= 1;
-        double* qw = vb + (size_t)(V_Q + c.cur) * sv;
-        double* pw = vb + (size_t)(V_P + c.cur) * sv;
-        for (int e0 = tid; e0 < dim; e0 += DBC * (int)blockDim.x) {
-            double p0[DBC], g0[DBC], q0[DBC];
-#pragma unroll
-            for (int u = 0; u < DBC; ++u) {
-                const int e = e0 + u * (int)blockDim.x;
-                if (e < dim) { p0[u] = pe[e]; g0[u] = ge[e]; q0[u] = qe[e]; }
-            }
-#pragma unroll
-            for (int u = 0; u < DBC; ++u) {
-                const int e = e0 + u * (int)blockDim.x;
-                if (e < dim) {
-                    const double ph = p0[u] + hs * g0[u];
-                    pw[e] = ph;
-                    const double qn = q0[u] + eps * ph;
-                    qw[e] = qn;
-                    if (ch.mc && e < pb.ND) { const int dd = e / pb.N; ch.xop[xop_off(pb, ch.n_chains, parity ^ 1, chain, dd, e - dd * pb.N)] = qn; }   // (read by the next slot's stream)
-                    v.rhosub[e] = 0.0;
-                    if (e >= pb.ND) compute_par_entry(pb, e - pb.ND, qn, par, true, s_cst + MAGI_MAX_D);
-                }
-            }
-        }
-        if constexpr (SEPK) {
-            // operand mirror of the new state for the next slot's stream (k_stream_sep): xc and the basis values phi_{d,k} need ALL
-            // components of a grid point, so the positions are formed again per point (same expressions, same rounding as above)
-            using DR = DriftT<DRIFT>;
-            constexpr int DD = DR::D, NBM = DR::NBMAX;
-            const int cw = xop_width(ch.n_chains), groups = (ch.n_chains + 15) >> 4, cl = chain & 15;
-            const int planes = 1 + (NBM * cw + 15) / 16;
-            for (int i = tid; i < pb.N; i += (int)blockDim.x) {
-                double xq[DD], ph[DD][NBM];
-#pragma unroll
-                for (int dd = 0; dd < DD; ++dd) {
-                    const int e = dd * pb.N + i;
-                    const double phh = pe[e] + hs * ge[e];
-                    xq[dd] = qe[e] + eps * phh;
-                }
-                DR::basis(xq, ph);
-#pragma unroll
-                for (int dd = 0; dd < DD; ++dd) {
-                    double* m0 = ch.vop + vop_off(DD, planes, pb.Np, groups, parity ^ 1, chain >> 4, dd, 0, i);
-                    m0[cl] = xq[dd] - s_cst[2 * MAGI_MAX_D + dd];
-#pragma unroll
-                    for (int k = 0; k < NBM; ++k)
-                        if (k < DR::nbasis(dd))
-                            m0[(size_t)(cw == 8 ? 1 + (k >> 1) : 1 + k) * pb.Np * 16 + (cw == 8 ? (k & 1) * 8 + cl : cl)] = ph[dd][k];
-                }
-            }
-        }
         c.nsteps = hmc ? cfg.hmc_L : (1 << c.depth);
         c.it = 0;
         c.sub_weight = -INFINITY;
@@ -533,16 +425,20 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
         c.sub_lf = 0;
         c.cont = 1;
         c.nd = c.not_div;
-        c.phase = PH_LEAF;
-        if (tid == 0) {
-            LeafPlan p{};                // the stream next to us is not looking at this state: skip slot, then evaluate it as is
-            p.active = 1; p.skip = 1; p.cur = c.cur;
-            *plan_out = p;
-        }
-    } else if (tid == 0) {
-        LeafPlan off{};                  // idle after the bootstrap gradient
-        *plan_out = off;
+        vop |= VOP_DOUBLE;
+        if (start) c.phase = PH_DRAWN;          // (else PH_MERGED, set with the merge)
     }
-    if (tid == 0) ch.ctl[chain] = c;
+    if (tid == 0) {
+        LeafPlan p{};
+        p.vop = vop;
+        p.active = doubling ? 1 : 0;             // with a doubling: the stream of the NEXT slot evaluates buffer `cur` as is
+        p.skip = doubling ? 1 : 0;
+        p.cur = c.cur;
+        p.eps = d_eps; p.hs = d_hs;
+        p.vleaf = vleaf; p.vdir = vdir; p.ndir = c.dir; p.vout = vout;
+        p.step_k = (unsigned)c.k; p.chain_id = (unsigned)c.chain_id; p.seed = cfg.seed;
+        *plan_out = p;
+        ch.ctl[chain] = c;
+    }
 }
 

@@ -704,7 +704,7 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
         double* s_cst = s_ops + OPS_COUNT * OPS_W;            // 3 * MAGI_MAX_D
         int* s_g = reinterpret_cast<int*>(s_cst + 3 * MAGI_MAX_D);
         ChainCtl* s_ctl = reinterpret_cast<ChainCtl*>(s_cst + 3 * MAGI_MAX_D + 2);
-        if (chain < ch.n_chains) decide_block<DRIFT, true>(pb, ch, cfg, chain, parity, all_done, dsh, dshs, s_ctl, s_g, s_par, s_ops, s_cst);
+        if (chain < ch.n_chains) decide_block<DRIFT>(pb, ch, cfg, chain, parity, all_done, dsh, dshs, s_ctl, s_g, s_par, s_ops, s_cst);
         return;
     }
     double* colsum = smem + MC_SM_CS;                                            // [matrix-core column][block column]: running column-type sums
@@ -967,7 +967,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains c
     const int all_done = ch.gctl->all_done;
     const LeafPlan lp = ch.plan[(size_t)parity * ch.n_chains + blockIdx.y];
     kernarg_prefetch<sizeof(DevProblem) + sizeof(DevChains) + sizeof(int)>();
-    const int gate = all_done | (lp.active ^ 1) | lp.skip;
+    if (all_done != 0) return;
+    if (lp.vop != 0) { boundary_block<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, redk, s_mu, s_x, parity ^ 1); return; }     // a subtree / transition end (decide.h)
+    const int gate = (lp.active ^ 1) | lp.skip;
     if (gate != 0) return;
     if constexpr (DriftT<DRIFT>::SEP) {
         if (ch.sep) { point_block_sep<DRIFT>(pb, ch, lp, blockIdx.y, blockIdx.x, res, redk, s_mu, s_x, parity ^ 1); return; }

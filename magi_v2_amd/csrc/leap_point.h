@@ -361,3 +361,145 @@ __device__ __forceinline__ void point_block_sep(const DevProblem& pb, const DevC
         if (q == 0) *(&ch.part[((size_t)cc * PART_K + k) * ch.n_wg + blk]) = s;
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Boundary op of a chain (LeafPlan::vop, BoundaryOp): the state-sized work at a subtree's or a transition's end -- the finished subtree's
+// last leaf becomes an end of the trajectory, rho += rho_sub and the trajectory-level U-turn sums; the proposal copy; the sample row; the
+// momentum draw of the next transition; the first half / full step of the next doubling with its operand mirror and parameter block.
+// All of it is element by element over the state vector (TFP's NoUTurnSampler: the tree merge of its loop_tree_doubling, and
+// _start_trajectory_batched / the leapfrog's first step; wiring magi_v2.py:357-396), so it runs here on every workgroup of the point
+// kernel -- one lane per entry, every load of a lane in ONE round trip -- instead of on the decisions' single workgroup, where the same
+// passes were loops of four dependent round trips next to the saturating stream (25-100 us, the slot waiting for them).  The decisions
+// (decide.h) keep the scalars; the sums this op leaves (rows PK_DOT, PK_DOT + 1: U-turn; PK_PP: p.p) reach them with the next slot.
+// Workgroup 0 also takes the D + P parameter entries (a second pass of its first lanes).
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <int DRIFT>
+__device__ __forceinline__ void boundary_block(const DevProblem& pb, const DevChains& ch, const LeafPlan& lp, int cc, int blk,
+                                               double* redk /* 64 * PART_K */, double* s_mu /* MAGI_MAX_D */, double* s_x /* PT_POINTS * PT_DSLOT */,
+                                               int mirror_buf /* slot parity ^ 1 */) {
+    using DR = DriftT<DRIFT>;
+    constexpr int D = DR::D, P = DR::P;
+    const unsigned t = threadIdx.x;
+    const int N = pb.N, ND = pb.ND;
+    const size_t dimp = pb.dimp;
+    const int vop = lp.vop;
+    const bool ends = (vop & VOP_ENDS) != 0, cand = (vop & VOP_CAND) != 0, takel = (vop & VOP_TAKE_LEAF) != 0, outp = (vop & VOP_OUT) != 0;
+    const bool draw = (vop & VOP_DRAW) != 0, dbl = (vop & VOP_DOUBLE) != 0;
+    double* vb = ch.vec + vec_off(pb, cc, 0);
+    if (t == PT_THREADS - 1) {
+#pragma unroll
+        for (int k = 0; k < MAGI_MAX_D; ++k) s_mu[k] = pb.mu[k];
+    }
+    const int fpt = t & (PT_POINTS - 1), fd = (t / PT_POINTS) & (PT_DSLOT - 1);
+    const int fi = blk * PT_POINTS + fpt;
+    const bool fvalid = (t < 64) && (fd < D) && (fi < N);
+    double xn_grid = 0.0;
+    if (t < 64) {
+        double* pk = redk + (size_t)t * PART_K;
+#pragma unroll
+        for (int k = 0; k < PART_K; ++k) pk[k] = 0.0;
+        const double* qleaf = vb + (size_t)(V_Q + lp.vleaf) * dimp;
+        const double* g = vb + (size_t)V_G * dimp;
+        const double* pleaf = vb + (size_t)V_PLEAF * dimp;
+        double* pL = vb + (size_t)V_PL * dimp; double* qL = vb + (size_t)V_QL * dimp; double* gL = vb + (size_t)V_GL * dimp;
+        double* pR = vb + (size_t)V_PR * dimp; double* qR = vb + (size_t)V_QR * dimp; double* gR = vb + (size_t)V_GR * dimp;
+        double* candq = vb + (size_t)V_CANDQ * dimp; double* candg = vb + (size_t)V_CANDG * dimp;
+        const double* subq = vb + (size_t)V_SUBQ * dimp; const double* subg = vb + (size_t)V_SUBG * dimp;
+        double* rho = vb + (size_t)V_RHO * dimp; double* rhosub = vb + (size_t)V_RHOSUB * dimp;
+        double* pE = lp.vdir > 0 ? pR : pL; double* qE = lp.vdir > 0 ? qR : qL; double* gE = lp.vdir > 0 ? gR : gL;
+        const double* pO = lp.vdir > 0 ? pL : pR;                          // the other end
+        const double* pS = lp.ndir > 0 ? pR : pL; const double* qS = lp.ndir > 0 ? qR : qL; const double* gS = lp.ndir > 0 ? gR : gL;
+        const bool from_new_end = ends && lp.ndir == lp.vdir;              // the doubling starts from the end this op writes: its values are in registers
+        const bool start_loads = dbl && !draw && !from_new_end;
+        const int npass = (blk == 0) ? 2 : 1;
+        for (int pass = 0; pass < npass; ++pass) {
+            const bool grid = pass == 0;
+            const bool valid = grid ? fvalid : ((int)t < D + P);
+            const int e = grid ? fd * N + fi : ND + (int)t;
+            if (valid) {
+                // ---- every load of this entry, one round trip ----
+                double ql = 0.0, gl = 0.0, pn = 0.0, rho_v = 0.0, rs_v = 0.0, po = 0.0, sq = 0.0, sg = 0.0, cq = 0.0, cg = 0.0, p0 = 0.0, q0 = 0.0, g0 = 0.0;
+                if (ends || (cand && takel)) { ql = qleaf[e]; gl = g[e]; }
+                if (ends) { pn = pleaf[e]; rho_v = rho[e]; rs_v = rhosub[e]; po = pO[e]; }
+                if (cand && !takel) { sq = subq[e]; sg = subg[e]; }
+                if ((outp || draw) && !cand) { cq = candq[e]; cg = candg[e]; }
+                if (start_loads) { p0 = pS[e]; q0 = qS[e]; g0 = gS[e]; }
+                // ---- merge ----
+                if (ends) {
+                    pE[e] = pn; qE[e] = ql; gE[e] = gl;
+                    const double rr = rho_v + rs_v;
+                    rho[e] = rr;
+                    pk[PK_DOT] += rr * po;
+                    pk[PK_DOT + 1] += rr * pn;
+                    if (from_new_end) { p0 = pn; q0 = ql; g0 = gl; }
+                }
+                if (cand) {
+                    cq = takel ? ql : sq; cg = takel ? gl : sg;
+                    candq[e] = cq; candg[e] = cg;
+                }
+                if (outp) ch.samples[(size_t)lp.vout * dimp + e] = cq;
+                // ---- next transition: momentum, both ends = the proposal ----
+                if (draw) {
+                    const double z = rng_normal_elem((unsigned)e, lp.step_k, lp.chain_id, lp.seed);
+                    pL[e] = z; pR[e] = z; rho[e] = z;
+                    qL[e] = cq; qR[e] = cq; gL[e] = cg; gR[e] = cg;
+                    pk[PK_PP] += z * z;
+                    p0 = z; q0 = cq; g0 = cg;
+                }
+                // ---- next doubling: first half / full step from the selected end (identity mass: p_half = p + eps/2 grad, q' = q + eps p_half) ----
+                if (dbl) {
+                    const double ph = p0 + lp.hs * g0;
+                    *(vb + (size_t)(V_P + lp.cur) * dimp + e) = ph;
+                    const double qn = q0 + lp.eps * ph;
+                    *(vb + (size_t)(V_Q + lp.cur) * dimp + e) = qn;
+                    rhosub[e] = 0.0;
+                    if (grid) {
+                        xn_grid = qn;
+                        if (ch.mc) ch.xop[xop_off(pb, ch.n_chains, mirror_buf, cc, fd, fi)] = qn;      // (read by the next slot's matrix-core stream)
+                    } else {
+                        compute_par_entry(pb, (int)t, qn, ch.par + (size_t)cc * PAR_COUNT, true, nullptr);
+                    }
+                }
+            }
+        }
+        if constexpr (DR::SEP) {
+            // operand mirror of the new state for the next slot's separable stream: as in point_block_sep (one wave, LDS exchange of a point's components)
+            if (ch.sep && dbl) {
+                constexpr int NBM = DR::NBMAX;
+                s_x[fpt * PT_DSLOT + fd] = xn_grid;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (fvalid) {
+                    double xq[D], ph[D][NBM];
+#pragma unroll
+                    for (int dd = 0; dd < D; ++dd) xq[dd] = s_x[fpt * PT_DSLOT + dd];
+                    DR::basis(xq, ph);
+                    const int cw = xop_width(ch.n_chains), groups = (ch.n_chains + 15) >> 4, cl = cc & 15;
+                    const int planes = 1 + (NBM * cw + 15) / 16;
+                    double* m0 = ch.vop + vop_off(D, planes, pb.Np, groups, mirror_buf, cc >> 4, fd, 0, fi);
+                    m0[cl] = xn_grid - s_mu[fd];
+#pragma unroll
+                    for (int dd = 0; dd < D; ++dd) {
+                        if (fd == dd) {
+#pragma unroll
+                            for (int k = 0; k < NBM; ++k)
+                                if (k < DR::nbasis(dd))
+                                    m0[(size_t)(cw == 8 ? 1 + (k >> 1) : 1 + k) * pb.Np * 16 + (cw == 8 ? (k & 1) * 8 + cl : cl)] = ph[dd][k];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (t < 4 * PART_K) {
+        const int k = t >> 2, q = t & 3;
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += redk[(16 * q + u) * PART_K + k];
+        s += dpp_f64<0xB1>(s);
+        s += dpp_f64<0x4E>(s);
+        if (q == 0) *(&ch.part[((size_t)cc * PART_K + k) * ch.n_wg + blk]) = s;
+    }
+}

@@ -97,7 +97,19 @@ enum VecSlot {
 };
 
 enum ChainPhase { PH_INIT = 0, PH_LEAF = 1, PH_IDLE = 2,
-                  PH_PEND_DOUBLE = 3, PH_PEND_SAMPLE = 4 };   // a subtree / transition end spread over several slots (decide.h: batches of chains)
+                  PH_MERGED = 3,    // a subtree's end is being merged by the point phase (boundary op): the decisions of the next slot read its U-turn sums
+                  PH_DRAWN = 4 };   // a transition's momentum is being drawn by the point phase: the decisions of the next slot read p.p
+
+// Boundary work of a chain at a subtree / transition end: state-sized, element by element -- done by the POINT kernel of the slot (all its
+// workgroups; leap_point.h: boundary_block) on the decisions' order (LeafPlan::vop), not by the decisions' single workgroup.
+enum BoundaryOp {
+    VOP_ENDS = 1,        // the finished subtree's last leaf becomes the trajectory's end `vdir`; rho += rho_sub; U-turn sums rho.p_other, rho.p_end
+    VOP_CAND = 2,        // trajectory proposal <- subtree proposal (or the last leaf itself: VOP_TAKE_LEAF)
+    VOP_TAKE_LEAF = 4,
+    VOP_OUT = 8,         // sample row `vout` <- trajectory proposal
+    VOP_DRAW = 16,       // transition `step_k` starts: momentum ~ N(0, I) at both ends, ends <- proposal, sum p.p
+    VOP_DOUBLE = 32      // a doubling starts from end `ndir`: first half / full step into buffer `cur` (+ operand mirrors, parameter block)
+};
 
 // Per-chain scalar state of the device-resident sampler ---------------------------------------
 struct ChainCtl {
@@ -167,6 +179,12 @@ struct LeafPlan {
     double hs;         // 0.5 * eps * beta_k (signed)
     double eps;        // signed step
     unsigned long long seed;
+    // boundary op (vop != 0: `leaf` is 0; with VOP_DOUBLE active = skip = 1 and `cur` is the buffer the NEXT stream evaluates, else active = 0)
+    int vop;           // BoundaryOp bits
+    int vleaf;         // position buffer of the subtree's last leaf (VOP_ENDS, VOP_TAKE_LEAF)
+    int vdir;          // +1 / -1: the end the finished subtree grew (VOP_ENDS)
+    int ndir;          // +1 / -1: the end the next doubling starts from (VOP_DOUBLE)
+    long long vout;    // row of ch.samples (VOP_OUT)
 };
 
 constexpr int MAGI_TB = 128;  // block edge of the packed single-phase operators
