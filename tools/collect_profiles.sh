@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 mkdir -p $O
 # 1. the bench line (N = 1 GPU, defaults of the driver) and the config-3 per-GPU operating point (8 chains)
 timeout -k 10 600 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err || exit 1
-timeout -k 10 300 python3 bench.py --chains-per-gpu 8 --steps 50 --no-cpu-baseline --no-extra-configs > $O/bench_8chains.json 2> $O/bench_8chains.err || exit 1
+timeout -k 10 300 python3 bench.py --chains-per-gpu 8 --steps 200 --no-cpu-baseline --no-extra-configs > $O/bench_8chains.json 2> $O/bench_8chains.err || exit 1
 # 2. kernel trace of the bench on the GRAPH path (2-slot graphs keep rocprofv3's node bookkeeping small), and with the default 64-slot graphs
 MAGI_GRAPH_SLOTS=2 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_graph2 -- python3 bench.py --steps 5 --warmup 1 --burnin 30 --no-cpu-baseline --no-extra-configs --profile-slots 2 > $O/kt_graph2.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_graph64 -- python3 bench.py --steps 2 --warmup 0 --burnin 4 --no-cpu-baseline --no-extra-configs --profile-slots 2 > $O/kt_graph64.log 2>&1; echo "graph64 rc=$?" > $O/kt_graph64.rc

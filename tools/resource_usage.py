@@ -23,11 +23,11 @@ s = open("/tmp/leap-hip-amdgcn-amd-amdhsa-gfx950.s").read()
 def body(sym):
     i = s.index("\n" + sym + ":"); j = s.index(".Lfunc_end", i); return s[i:j].split("\n")
 print()
-print("# Where the spills are (ISA of the same compile; line numbers inside each kernel's body): the streaming workgroups' code -- from the first to the")
-print("# last MFMA (k_stream_sep) / cross-lane exchange of the row sums (k_stream) -- has NO scratch access; every scratch_load / scratch_store belongs to the")
-print("# decision workgroup's path (decide_block, inlined: it rides in the same kernel, DESIGN.md 4.2), which shares the kernel's register allocation and its")
-print("# scratch reservation.  Measured as a function of its own (not inlined: the body then allocates alone, 0 spills): the decisions ran 40 us and the slot")
-print("# 45 us instead of 27-32 (gpurun_out/r3g), 500 scratch accesses next to the saturating stream -- kept inlined.")
+print("# Scratch (ISA of the same compile; line numbers inside each kernel's body).  Since the state-sized boundary passes moved from the decision workgroup to the")
+print("# point kernel (leap_point.h: boundary_block) the stream kernels spill NO vector register; what is left of the scratch reservation (16-48 B per lane) are a few")
+print("# accesses on the decision path (decide_block, inlined: it rides in the same kernel, DESIGN.md 4.2).  The streaming workgroups' code -- from the first to the last")
+print("# burst of tile loads -- has no scratch access.  (Before that move: 56-116 spilled VGPRs per kernel, all on the decision path; as a function of its own the")
+print("# decision path ran 40 us and the slot 45 instead of 27-32, so it stayed inlined.)")
 for sym, what in (("_ZN12_GLOBAL__N_112k_stream_sepILi1ELi8EEEv10DevProblem9DevChains13SamplerCfgDevi", "k_stream_sep<SEIR4, 8>"),
                   ("_ZN12_GLOBAL__N_18k_streamILi1ELi1EEEv10DevProblem9DevChains13SamplerCfgDevi", "k_stream<1, SEIR4>")):
     L = body(sym)
@@ -38,4 +38,4 @@ for sym, what in (("_ZN12_GLOBAL__N_112k_stream_sepILi1ELi8EEEv10DevProblem9DevC
     sc = [i for i, l in enumerate(L) if "scratch_" in l]
     inside = [i for i in sc if runs[0] <= i <= end]
     print("%s: %d ISA lines; streaming body (first .. last burst of tile loads + 300 lines) = lines %d..%d; %d scratch accesses in the kernel, on lines %d..%d; %d of them inside the streaming body"
-          % (what, len(L), runs[0], end, len(sc), sc[0], sc[-1], len(inside)))
+          % (what, len(L), runs[0], end, len(sc), sc[0] if sc else -1, sc[-1] if sc else -1, len(inside)))
