@@ -11,10 +11,12 @@
 // decide_block runs as ONE extra workgroup per chain inside k_stream (leap.hip), i.e. concurrently with
 // the block mat-vecs of the NEXT slot: it adds the point phase's partial sums, finishes the D + P
 // parameter entries, does all tree bookkeeping (multinomial proposal, checkpointed U-turn tests,
-// doubling, merge, transition end, dual averaging, temperature, next momentum draw) and publishes the
-// plan the next point phase executes.  The stream next to it has already assumed "same subtree, next
-// leaf" (it derives theta' itself, leap_reduce.h); when the decisions end the subtree instead they set up
-// the new state and mark the slot `skip`.
+// doubling, merge, transition end, dual averaging, temperature) and publishes the plan the next point
+// phase executes.  The stream next to it has already assumed "same subtree, next leaf" (it derives
+// theta' itself, leap_reduce.h); when the decisions end the subtree instead, the plan orders a BOUNDARY OP
+// (LeafPlan::vop; leap_point.h: boundary_block): every state-sized pass of a subtree's or a transition's
+// end -- merge of the ends, rho, proposal copy, sample row, momentum draw, the next doubling's first state --
+// is the point kernel's, the sums it leaves (U-turn, p.p) arrive here with the next slot (PH_MERGED, PH_DRAWN).
 //
 // It runs once per launch on one CU, on a cold instruction cache: its speed is set by code size along
 // the executed path.  Hence one instantiation per drift (compile-time D, P), single call sites for the
@@ -41,10 +43,10 @@ __device__ __forceinline__ TailVecs tail_vecs(const DevProblem& pb, double* vb) 
     return v;
 }
 
-// State-sized loops of the rare paths (subtree ends, transition ends), one workgroup over `dim` entries: written element by
-// element (`dst[e] = src[e]`) every iteration is its own memory round trip -- DB elements' loads are issued together instead.
-constexpr int DB = 4;        // (loops that keep seven vectors' elements in registers)
-constexpr int DBC = 6;       // copies, sample set-up, doubling set-up: fewer vectors, more elements in flight
+// The state-sized loops left here (the subtree-proposal copy of an accepted leaf; the checkpoint tests of levels >= 5), one workgroup over
+// `dim` entries: written element by element (`dst[e] = src[e]`) every iteration is its own memory round trip -- DBC elements' loads are
+// issued together instead.
+constexpr int DBC = 6;
 __device__ __forceinline__ void copy2_batched(double* d0, const double* s0, double* d1, const double* s1, int dim) {
     for (int e0 = threadIdx.x; e0 < dim; e0 += DBC * (int)blockDim.x) {
         double a[DBC], b[DBC];
