@@ -43,25 +43,7 @@ __device__ __forceinline__ TailVecs tail_vecs(const DevProblem& pb, double* vb) 
     return v;
 }
 
-// The state-sized loops left here (the subtree-proposal copy of an accepted leaf; the checkpoint tests of levels >= 5), one workgroup over
-// `dim` entries: written element by element (`dst[e] = src[e]`) every iteration is its own memory round trip -- DBC elements' loads are
-// issued together instead.
-constexpr int DBC = 6;
-__device__ __forceinline__ void copy2_batched(double* d0, const double* s0, double* d1, const double* s1, int dim) {
-    for (int e0 = threadIdx.x; e0 < dim; e0 += DBC * (int)blockDim.x) {
-        double a[DBC], b[DBC];
-#pragma unroll
-        for (int u = 0; u < DBC; ++u) {
-            const int e = e0 + u * (int)blockDim.x;
-            if (e < dim) { a[u] = s0[e]; if (s1) b[u] = s1[e]; }
-        }
-#pragma unroll
-        for (int u = 0; u < DBC; ++u) {
-            const int e = e0 + u * (int)blockDim.x;
-            if (e < dim) { d0[e] = a[u]; if (d1) d1[e] = b[u]; }
-        }
-    }
-}
+// The state-sized loop left here: the checkpoint tests of levels >= 5 (one leaf in 32), one workgroup over `dim` entries.
 
 // DualAveragingStepSizeAdaptation.one_step after the inner NUTS step (oracle: dual_averaging_update).
 // Evaluated by one thread; results returned through out[0..3].
@@ -313,12 +295,17 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
 
             if (c.it < c.nsteps && c.cont) {
                 // ---- the speculative next leaf stands: flip buffers, publish its plan -------------------------
-                if (accept_leaf) {                   // proposal copy (expected O(log n) times per subtree)
-                    copy2_batched(v.subq, qcur, v.subg, v.g, dim);
+                // an accepted leaf becomes the subtree's proposal (expected O(log n) times per subtree): the NEXT leaf's point phase copies its
+                // position and gradient (LeafPlan::sub_copy) before overwriting them; the D + P parameter entries are copied here
+                if (accept_leaf && tid < DriftT<DRIFT>::D + DriftT<DRIFT>::P) {
+                    v.subq[pb.ND + tid] = qcur[pb.ND + tid];
+                    v.subg[pb.ND + tid] = v.g[pb.ND + tid];
                 }
                 c.cur = lp.cur ^ 1;
                 if (tid == 0) {
-                    *plan_out = make_leaf_plan(c, cfg.seed, hmc);
+                    LeafPlan pn = make_leaf_plan(c, cfg.seed, hmc);
+                    pn.sub_copy = accept_leaf ? 1 : 0;
+                    *plan_out = pn;
                     ch.ctl[chain] = c;
                 }
                 MAGI_STAMP(par, 6);

@@ -20,7 +20,7 @@ template <int DRIFT>
 struct GridPoint {     // component d of grid index i of one chain (one lane)
     using DR = DriftT<DRIFT>;
     static constexpr int D = DR::D, P = DR::P;
-    struct Ops { double y, phe, rhoe, cpk[4], crk[4], x[D], th[P], sig2; };
+    struct Ops { double y, phe, rhoe, cpk[4], crk[4], x[D], th[P], sig2, qprev, gold; };
 
     // the lane's own operands: independent of the products, so their latency overlaps the partial sums
     static __device__ __forceinline__ Ops load(const DevProblem& pb, const DevChains& ch, const LeafPlan& lp, int cc, int i, int d) {
@@ -31,10 +31,14 @@ struct GridPoint {     // component d of grid index i of one chain (one lane)
         const double* q = vb + (size_t)(V_Q + lp.cur) * dimp;
         const int e = d * N + i;
         o.y = pb.yobs[e];
-        o.phe = 0.0; o.rhoe = 0.0;
+        o.phe = 0.0; o.rhoe = 0.0; o.qprev = 0.0; o.gold = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { o.cpk[k] = 0.0; o.crk[k] = 0.0; }
         if (lp.leaf) {
+            if (lp.sub_copy) {       // the previous leaf becomes the subtree's proposal: its position and gradient, before this phase overwrites them
+                o.qprev = (vb + (size_t)(V_Q + (lp.cur ^ 1)) * dimp)[e];
+                o.gold = (vb + (size_t)V_G * dimp)[e];
+            }
             o.phe = (vb + (size_t)(V_P + lp.cur) * dimp)[e];
             o.rhoe = (vb + (size_t)V_RHOSUB * dimp)[e];
             const double* ckp = vb + (size_t)V_CKP0 * dimp;
@@ -94,6 +98,7 @@ struct GridPoint {     // component d of grid index i of one chain (one lane)
             const double rs = o.rhoe + pn;
             *(rho + e) = rs;
             pk[PK_PP] = pn * pn;
+            if (lp.sub_copy) { *(vb + (size_t)V_SUBQ * dimp + e) = o.qprev; *(vb + (size_t)V_SUBG * dimp + e) = o.gold; }
             if (lp.even) { *(ckp + (size_t)lp.ck_slot * dimp + e) = pn; *(ckr + (size_t)lp.ck_slot * dimp + e) = rs; }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -312,6 +317,7 @@ __device__ __forceinline__ void point_block_sep(const DevProblem& pb, const DevC
                 const double rs = ops.rhoe + pn;
                 *(rho + e) = rs;
                 pk[PK_PP] = pn * pn;
+                if (lp.sub_copy) { *(vb + (size_t)V_SUBQ * dimp + e) = ops.qprev; *(vb + (size_t)V_SUBG * dimp + e) = ops.gold; }
                 if (lp.even) { *(ckp + (size_t)lp.ck_slot * dimp + e) = pn; *(ckr + (size_t)lp.ck_slot * dimp + e) = rs; }
 #pragma unroll
                 for (int k = 0; k < 4; ++k)

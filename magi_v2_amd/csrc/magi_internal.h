@@ -185,6 +185,8 @@ struct LeafPlan {
     int vdir;          // +1 / -1: the end the finished subtree grew (VOP_ENDS)
     int ndir;          // +1 / -1: the end the next doubling starts from (VOP_DOUBLE)
     long long vout;    // row of ch.samples (VOP_OUT)
+    int sub_copy;      // leaf plans: the PREVIOUS leaf (position buffer cur ^ 1, gradient V_G as it stands) was accepted as the subtree's proposal:
+                       // the point phase copies it to V_SUBQ / V_SUBG before it overwrites both (the D + P parameter entries: the decisions)
 };
 
 constexpr int MAGI_TB = 128;  // block edge of the packed single-phase operators
