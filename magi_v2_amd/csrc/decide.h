@@ -216,15 +216,11 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
     } else {
         const bool leaf = lp.leaf != 0;
         MAGI_STAMP(par, 1);
-        // the leaf's two uniform draws (off the critical path here: these decisions run next to the following stream)
-        if (leaf && tid == 128) shs[21] = m_log1p(-rng_uniform(lp.leaf_ctr, lp.step_k, lp.chain_id, STREAM_LEAF, lp.seed));
-        if (leaf && tid == 192) shs[22] = m_log1p(-rng_uniform(lp.depth, lp.step_k, lp.chain_id, STREAM_MERGE, lp.seed));
         if (!leaf && tid == 64) shs[16] = cfg.anneal ? temperature(0, cfg.min_temp) : 1.0;
         // ---- add the streaming kernel's partial sums, finish the parameter entries -----------------------
         const ReduceOut ro = leap_reduce<DRIFT>(pb, ch, chain, vb, par, s_par, lp, pre, sh, shs, s_ops, s_cst);
         MAGI_STAMP(par, 4);
         const double L = ro.L;
-        const double u_leaf = shs[21], u_merge = shs[22];        // (published by the barriers inside leap_reduce)
         double* qcur = vb + (size_t)(V_Q + lp.cur) * sv;      // the state that was evaluated
         double* pleaf = vb + (size_t)V_PLEAF * sv;
 
@@ -277,10 +273,18 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
             if (isnan(energy)) energy = -INFINITY;
             const double ediff = energy - c.init_energy;
             const bool not_divergent = (-ediff < cfg.max_energy_diff);
+            // The transcendental work of a leaf, one piece per wave, between two barriers (this workgroup is the longest of the kernel it
+            // rides in whenever the grid is small -- device stamps: its time is its chain of dependent exp / log calls):
+            //   wave 0: log-sum-exp of the subtree weight | wave 1: transform of the next state's parameter entries (exp -> log)
+            //   wave 2: the leaf's two uniform draws (Philox, log1p; lanes 128, 129) | wave 3: exp of the energy difference
             if (tid == 0) shs[18] = logaddexp(c.sub_weight, ediff);
             if (tid == 192) shs[19] = m_exp(fmin(ediff, 0.0));
+            if (tid == 128 || tid == 129)
+                shs[21 + (tid - 128)] = m_log1p(-rng_uniform(tid == 128 ? lp.leaf_ctr : lp.depth, lp.step_k, lp.chain_id, tid == 128 ? STREAM_LEAF : STREAM_MERGE, lp.seed));
+            leap_next_par<DRIFT>(pb, par, sh, s_cst + MAGI_MAX_D);
             __syncthreads();
             MAGI_STAMP(par, 5);
+            const double u_leaf = shs[21], u_merge = shs[22];
             const double wsum_leaf = shs[18];
             const bool accept_leaf = !hmc && (u_leaf <= ediff - wsum_leaf);
             c.leaf_ctr += 1;

@@ -162,18 +162,6 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
         }
     }
 
-    // t3 = sum_d N_d log(2 pi sigma_d^2) of the evaluated state: a third wave computes it here, under the wait for the first
-    // round of loads (A/B: 0.55 us per slot better than next to wave 1's exp -> log chain below); combined after the barriers
-    if (threadIdx.x >= 128 && threadIdx.x < 192) {
-        const int jd = threadIdx.x - 128;
-        double t3 = 0.0;
-        if (jd < D) {
-            const double nds = cst ? cst[jd] : MAGI_SEL_D(pb.N_ds, jd);
-            t3 = nds * m_log(2.0 * 3.141592653589793 * par_r[PAR_SIG2 + jd]);
-        }
-        t3 = row16_sum(t3);
-        if (jd == 0) shs[1] = t3;
-    }
     // ---- add the workgroup partials (fixed order: lane = workgroup, butterfly) ------------------------------------------
     constexpr int K0 = 2 + D + P;
     double red[K0 + 8];
@@ -239,12 +227,12 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
 #pragma unroll
             for (int k = 0; k < 4; ++k) { shs[4 + 2 * k] = red[K0 + 2 * k] + a[k]; shs[5 + 2 * k] = red[K0 + 2 * k + 1] + b[k]; }
         }
-    } else if (threadIdx.x < 128 && leaf) {
-        // wave 1, concurrently: transformed parameters of the speculative next state (used by the next
-        // k_leap_* if the subtree continues; overwritten by the tail's slow paths otherwise).  It re-derives
-        // the entry's gradient from the same totals, so it does not wait for wave 0.
+    } else if (threadIdx.x < 128) {
+        // wave 1, concurrently: the parameter entries of the speculative next state (pre-transform).  It re-derives the entry's gradient
+        // from the same totals, so it does not wait for wave 0.  Their transform (compute_par_entry: an exp -> log chain per entry) is
+        // the CALLER's, next to its own transcendental work (decide.h) -- here it made every barrier of the reduce wait for this wave.
         const int jj = threadIdx.x - 64;
-        if (jj < D + P) {
+        if (leaf && jj < D + P) {
             double gj;
             if (jj < D) {
                 const double sg = par_r[PAR_SGS + jj], sj = par_r[PAR_SIG2 + jj];
@@ -257,20 +245,20 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
                 gj = theta_entry_grad(pb.beta_inv, tpp, sg);
             }
             const double phv = ops ? ops[(OPS_P + lp.cur) * OPS_W + jj] : ph[ND + jj], qv = ops ? ops[(OPS_Q + lp.cur) * OPS_W + jj] : q[ND + jj];
-            const double qnx = next_entry_pre(phv, qv, lp.hs, lp.eps, gj);
-            // the old entries are still needed by wave 0 -> park the new ones, publish after the barrier
-            compute_par_entry(pb, jj, qnx, sh + 21 * 16, false, cst ? cst + MAGI_MAX_D : nullptr);      // parking block of 64 doubles behind block_sum's scratch
+            sh[21 * 16 + jj] = next_entry_pre(phv, qv, lp.hs, lp.eps, gj);      // parking block of 64 doubles behind block_sum's scratch: read by leap_next_par
         }
+    } else if (threadIdx.x < 192) {
+        // wave 2, concurrently: t3 = sum_d N_d log(2 pi sigma_d^2) of the evaluated state (one m_log; combined after the barrier)
+        const int jd = threadIdx.x - 128;
+        double t3 = 0.0;
+        if (jd < D) {
+            const double nds = cst ? cst[jd] : MAGI_SEL_D(pb.N_ds, jd);
+            t3 = nds * m_log(2.0 * 3.141592653589793 * par_r[PAR_SIG2 + jd]);
+        }
+        t3 = row16_sum(t3);
+        if (jd == 0) shs[1] = t3;
     }
     __syncthreads();
-    if (leaf && threadIdx.x >= 64 && threadIdx.x < 64 + PAR_ULEAF) {
-        // publish par' (entries below PAR_ULEAF; the rest of the block is not parameter data)
-        const int k = threadIdx.x - 64;
-        const bool used = (k < PAR_TH + P) || (k >= PAR_SGT && k < PAR_SGT + P) || (k >= PAR_LJT && k < PAR_LJT + P) ||
-                          (k >= PAR_SIG2 && k < PAR_SIG2 + D) || (k >= PAR_SGS && k < PAR_SGS + D) ||
-                          (k >= PAR_LJS && k < PAR_LJS + D);
-        if (used) par[k] = sh[21 * 16 + k];
-    }
     ReduceOut o;
     o.t12 = red[0]; o.t3 = shs[1]; o.t4 = shs[2]; o.pp = shs[3];
     o.L = -0.5 * ((pb.beta_inv * red[0]) + (o.t3 + o.t4)) + shs[0];
@@ -278,4 +266,13 @@ __device__ __forceinline__ ReduceOut leap_reduce(const DevProblem& pb, const Dev
     for (int k = 0; k < 4; ++k) { o.dA[k] = shs[4 + 2 * k]; o.dB[k] = shs[5 + 2 * k]; }
     __syncthreads();   // shs may be reused by the caller
     return o;
+}
+
+// Transformed parameters of the speculative next state (read by the next slot's point phase if the subtree continues; rewritten by a
+// boundary op otherwise): threads 64 .. 64 + D + P - 1, from the entries leap_reduce parked in sh.  Straight to the global block --
+// nothing in the kernel it rides in reads `par` of a chain whose plan is a leaf (the stream derives theta' itself).
+template <int DRIFT>
+__device__ __forceinline__ void leap_next_par(const DevProblem& pb, double* par, const double* sh, const double* lb_tab) {
+    const int jj = (int)threadIdx.x - 64;
+    if (jj >= 0 && jj < DriftT<DRIFT>::D + DriftT<DRIFT>::P) compute_par_entry(pb, jj, sh[21 * 16 + jj], par, false, lb_tab);
 }
