@@ -20,5 +20,6 @@ for N, band, n in ((161, 80, 1), (161, 80, 8), (512, None, 1), (1024, None, 1)):
     eng.sampler_run(60)
     t0 = time.perf_counter(); lf, ms = eng.sampler_run(40); dt = time.perf_counter() - t0
     slots = eng.sampler_run_stats()[0]
-    print(f"N={N} b={band} chains={n}: {dt / max(slots, 1) * 1e6:6.2f} us per slot issued, {lf / dt:9.0f} leapfrogs/s", flush=True)
+    st, pt, _ = eng.sampler_profile(256)
+    print(f"N={N} b={band} chains={n}: {dt / max(slots, 1) * 1e6:6.2f} us per slot issued, {lf / dt:9.0f} leapfrogs/s   (stream {st:.2f} us, point {pt:.2f} us in the sampler)", flush=True)
     eng.close()

@@ -24,7 +24,7 @@ def body(sym):
     i = s.index("\n" + sym + ":"); j = s.index(".Lfunc_end", i); return s[i:j].split("\n")
 print()
 print("# Scratch (ISA of the same compile; line numbers inside each kernel's body).  Since the state-sized boundary passes moved from the decision workgroup to the")
-print("# point kernel (leap_point.h: boundary_block) the stream kernels spill NO vector register; what is left of the scratch reservation (16-48 B per lane) are a few")
+print("# point kernel (leap_point.h: boundary_block) the stream kernels spill NO vector register; what is left of the scratch reservation (64 B per lane) are a few")
 print("# accesses on the decision path (decide_block, inlined: it rides in the same kernel, DESIGN.md 4.2).  The streaming workgroups' code -- from the first to the last")
 print("# burst of tile loads -- has no scratch access.  (Before that move: 56-116 spilled VGPRs per kernel, all on the decision path; as a function of its own the")
 print("# decision path ran 40 us and the slot 45 instead of 27-32, so it stayed inlined.)")
