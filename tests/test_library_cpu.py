@@ -43,3 +43,31 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_stream_kernels_spill_no_vector_register(tmp_path):
+    """The decisions of the sampler ride inlined in the streaming kernels and share their register allocation.  Since the state-sized
+    boundary passes moved to the point kernel no streaming kernel spills a vector register; this pins it (the
+    decision path is where round 3's register-allocation heisenbug lived).  hipcc cross-compiles without a GPU."""
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc) and shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "magi_v2_amd", "csrc", "leap.hip")
+    r = subprocess.run([hipcc if os.path.exists(hipcc) else "hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=on",
+                        "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", str(tmp_path / "leap.o")],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split(" [")[0]
+        if "k_stream" not in name:
+            continue
+        seen += 1
+        spills = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
+        occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
+        assert spills == 0, (name, spills)
+        assert occ >= 3, (name, occ)
+    assert seen >= 6
