@@ -155,7 +155,7 @@ int magi_ensure_chains(magi_handle* h, int n) {
         MAGI_HIP_CHECK(h, hipMalloc(&h->d_fin, sizeof(double) * 8 * n));
         h->cap_chains = n;
     }
-    const bool fam = magi_stream_family_mc(n);
+    const bool fam = magi_stream_family_mc(n, h->pb.n_tasks);
     if (h->n_chains != n || fam != h->family_mc) drop_graph(h);
     if (h->n_chains != n && h->ch.vop)       // the mirror's layout depends on the chain count: entries the new layout never writes must read zero
         MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.vop, 0, sizeof(double) * h->vop_elems, h->stream));

@@ -1075,9 +1075,16 @@ int launch_stream_mc(magi_handle* h, int n_chains, int parity, bool with_decisio
 // runs in (1-2 against >= 3).  MAGI_STREAM_FAMILY=mc routes EVERY batch size through the matrix-core kernel: a chain's samples
 // are then bit-identical whatever shares the GPU with it (uneven shards, e.g. 5 chains on 2 GPUs = 3 + 2), at the price of the
 // slower kernel for one or two chains.  Read at every sampler initialisation (magi_ensure_chains).
-bool magi_stream_family_mc(int n_chains) {
+// Small problems stay on the VALU kernel whatever the batch: with about one workgroup per CU (blocks x chain pairs <= 320) a launch is
+// as long as its longest workgroup, and the matrix-core kernels' workgroups are long (prologue + 8 dependent steps + stores).  Slot time,
+// VALU against matrix-core kernel: N = 161, b = 80, 8 chains 12.9 / 16.0 us; N = 256, 8 chains 13.0 / 16.0; N = 512, 3 and 4 chains
+// (288 workgroups) 14.6 / 16.0 and 14.9 / 16.2; N = 512, 8 chains (576) 20.0 / 17.0; N = 1024, 3 chains 30.7 / 23.5.
+// MAGI_STREAM_FAMILY=valu forces the VALU kernel for every batch (A/B).
+bool magi_stream_family_mc(int n_chains, int n_tasks) {
     const char* e = getenv("MAGI_STREAM_FAMILY");
-    return n_chains >= 3 || (e && std::string(e) == "mc");
+    if (e && std::string(e) == "mc") return true;
+    if (e && std::string(e) == "valu") return false;
+    return n_chains >= 3 && (long)n_tasks * ((n_chains + 1) / 2) > 320;
 }
 
 bool magi_drift_separable(int drift) {
@@ -1125,7 +1132,7 @@ int magi_launch_stream(magi_handle* h, int n_chains, int parity, bool with_decis
         MAGI_DRIFT_DISPATCH(h->pb.drift, MAGI_CALL);
 #undef MAGI_CALL
     }
-    if (n_chains == 2) return launch_stream_nc<2>(h, n_chains, parity, with_decisions, s);
+    if (n_chains >= 2) return launch_stream_nc<2>(h, n_chains, parity, with_decisions, s);       // (chain pairs on grid.y)
     return launch_stream_nc<1>(h, n_chains, parity, with_decisions, s);
 }
 

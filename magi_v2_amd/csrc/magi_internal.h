@@ -911,7 +911,7 @@ int magi_launch_stream(magi_handle* h, int n_chains, int parity, bool with_decis
 int magi_launch_point(magi_handle* h, int n_chains, int parity, hipStream_t s);                            // k_point: leapfrog epilogue per grid point
 int magi_launch_leap_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s, int parity = 0);
 int magi_leap_wgs(const DevProblem& pb);
-bool magi_stream_family_mc(int n_chains);        // leap.hip
+bool magi_stream_family_mc(int n_chains, int n_tasks);        // leap.hip
 int magi_build_profile_get(double* flops, double* ms, long* calls);           // build.hip
 int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const double* X, const double* mu, const double* mu_phi2,
                             const double* sd_phi2, const double* sig_loc, double nu, int iters, double lr, double jitter,

@@ -38,7 +38,7 @@ def test_fused_logpost_matches_golden(tag):
 
 
 @pytest.mark.parametrize("band,n_chains", [(3, 1), (10, 5), (None, 9)])
-def test_fused_banded_and_batched(band, n_chains):
+def test_fused_banded_and_batched(band, n_chains, stream_family):
     """band 3 / 10 at N=161 select the banded fused stacks (width 6b+1); 5 and 9 chains exercise
     the NC=4 / NC=8 variants with a ragged last group."""
     g = load_g4("seir3_N161")

@@ -298,8 +298,8 @@ def test_checkpoint_resume_in_a_new_handle_continues_the_run_bit_for_bit(n_chain
 @pytest.mark.parametrize("tag,chains,band", [("sirw_N41", 1, None), ("sirw_N41", 2, None), ("sirw_N41", 3, None), ("seir3_N161", 1, None), ("seir3_N161", 2, None),
                                              ("seir3_N161", 4, None), ("seir4_N81", 1, None), ("seir4_N81", 2, None), ("seir4_N81", 9, None),
                                              ("seir3_N161", 1, 20), ("seir3_N161", 4, 20), ("seir3_N161", 5, 80), ("sirw_N41", 3, 5)])
-def test_deep_trees_match_oracle_draw_for_draw_in_every_kernel_family(tag, chains, band):
-    """Every streaming-kernel instantiation a batch size selects (one chain: k_stream<1>, two: k_stream<2>, three or more: k_stream_sep
+def test_deep_trees_match_oracle_draw_for_draw_in_every_kernel_family(tag, chains, band, stream_family):
+    """Every streaming-kernel instantiation ("auto": one chain k_stream<1>, more: k_stream<2> in pairs on these small grids; "mc": k_stream_sep
     with its basis planes -- SIRW has three basis functions per component, i.e. a second plane on grid.z; nine chains: the 16-wide
     mirror) against the oracle on transitions that BUILD trees: a first step size of 2e-3 gives trees of depth 5-9 from the first
     transition on, where the reference's 0.1 makes the early transitions reject after one leapfrog -- and a rejected transition
@@ -331,7 +331,7 @@ def test_deep_trees_match_oracle_draw_for_draw_in_every_kernel_family(tag, chain
 
 
 @pytest.mark.parametrize("tag", ["sirw_N41", "seir4_N81"])
-def test_fused_log_posterior_is_the_same_in_even_and_odd_slots(tag, monkeypatch):
+def test_fused_log_posterior_is_the_same_in_even_and_odd_slots(tag, monkeypatch, stream_family):
     """The streaming kernels walk their blocks backwards in odd leapfrog slots and read the other halves of the plan ring and of the
     operand mirrors (MAGI_FUSED_PARITY=1 evaluates the fused log posterior that way): same values bit for bit, for one, two and five
     states (the three kernel families)."""

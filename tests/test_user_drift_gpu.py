@@ -189,9 +189,10 @@ def test_seven_parameter_system_chain_matches_oracle():
 
 
 @pytest.mark.parametrize("name", ["ptrans", "competition7", "fhn"])
-def test_user_drift_batched_states_on_the_matrix_core_kernel(name):
-    """Three or more states per call take the matrix-core streaming kernel (k_stream_mc); for a traced drift with 5 components /
+def test_user_drift_batched_states_on_the_matrix_core_kernel(name, monkeypatch):
+    """Three or more states per call on the matrix-core streaming kernel (k_stream_mc / k_stream_sep; these fixtures are small, so MAGI_STREAM_FAMILY=mc selects it); for a traced drift with 5 components /
     7 parameters that is the library built with the wider lane groups.  Batched fused == batched three-phase == per-state oracle."""
+    monkeypatch.setenv("MAGI_STREAM_FAMILY", "mc")
     eng, pr, Xhat, hp, truth = make_problem(name)
     rng = np.random.default_rng(11)
     D, P, n = Xhat.shape[1], len(truth), 5
@@ -210,7 +211,7 @@ def test_user_drift_batched_states_on_the_matrix_core_kernel(name):
 
 @pytest.mark.parametrize("name,chains,theta0", [("fhn", 1, 1.0), ("fhn", 3, 1.0), ("lotka_volterra", 1, 1.0), ("lotka_volterra", 4, 1.0),
                                                   ("ptrans", 1, 0.2), ("ptrans", 3, 0.2), ("competition7", 3, 1.0)])
-def test_traced_drift_deep_trees_match_oracle_in_every_kernel_family(name, chains, theta0):
+def test_traced_drift_deep_trees_match_oracle_in_every_kernel_family(name, chains, theta0, stream_family):
     """Every traced drift is its own library, i.e. its own instantiations of the streaming kernels and of the decisions inlined into
     them: one chain (VALU kernel) and a batch (k_stream_sep for the separable FitzHugh-Nagumo -- three basis functions, two planes --,
     Lotka-Volterra and the seven-parameter competition system; k_stream_mc for the protein-transduction system, whose V x / (K + x)

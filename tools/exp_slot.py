@@ -5,7 +5,10 @@ import numpy as np
 sys.path.insert(0, ".")
 from magi_v2_amd import host
 from magi_v2_amd.engine import MagiEngine
-for N, band, n in ((161, 80, 1), (161, 80, 8), (512, None, 1), (1024, None, 1)):
+cases = ((161, 80, 1), (161, 80, 8), (512, None, 1), (1024, None, 1))
+if len(sys.argv) > 1:        # N:band:chains ...
+    cases = tuple((int(a.split(":")[0]), (int(a.split(":")[1]) if a.split(":")[1] != "-" else None), int(a.split(":")[2])) for a in sys.argv[1:])
+for N, band, n in cases:
     I, X_obs, truth, th = host.synthetic_seir(N, seed=0)
     Xi = host.linear_interpolate(X_obs); hp = host.hparams_initial(Xi)
     N_ds, beta, idx, y = host.observation_bookkeeping(X_obs, X_obs)
