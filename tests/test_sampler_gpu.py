@@ -382,3 +382,32 @@ def test_fixed_length_hmc_first_transition_from_a_small_step_matches_oracle(tag,
         np.testing.assert_allclose(d.log_accept_ratio[i, 0], r.log_accept_ratio, rtol=1e-6, atol=1e-8)
         np.testing.assert_allclose(d.target_log_prob[i, 0], r.target_log_prob, rtol=1e-9)
         np.testing.assert_allclose(tp[i], otp, rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_small_problem_chain_is_bit_identical_in_every_batch():
+    """Small problems (operator blocks x chain pairs <= 320) keep every batch on the VALU streaming kernel, chain pairs side by side on
+    grid.y: a chain's samples are then the same BIT FOR BIT whatever the size of the batch it runs in and wherever it sits in it --
+    placement independence without a switch (for large problems see MAGI_STREAM_FAMILY)."""
+    g = load_g4("seir4_N81")
+    pr = problem_from_g4(g, None)
+    eng = engine_for(pr, None)
+    X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], np.ones(pr.P), pr.LB)
+    cfg = eng.default_cfg(num_results=6, num_burnin_steps=6, step_size=2e-3, max_tree_depth=6, stale_cache=0)
+    ref = None
+    for ids in ([7], [7, 3], [3, 7], [1, 7, 2], [0, 1, 2, 3, 7], [7, 6, 5, 4, 3, 2, 1, 0, 8]):
+        n = len(ids)
+        rep = lambda v: np.repeat(np.asarray(v)[None], n, axis=0)
+        eng.sampler_init(cfg, rep(X0), rep(s0), rep(t0), seed=5, chain_ids=ids)
+        eng.sampler_run(12)
+        X, sg, th = eng.sampler_samples()
+        d = eng.sampler_diag()
+        k = ids.index(7)
+        if ref is None:
+            ref = (X[k].copy(), sg[k].copy(), th[k].copy(), d.leapfrogs_taken[k].copy())
+            assert ref[3].max() >= 31
+        np.testing.assert_array_equal(X[k], ref[0])
+        np.testing.assert_array_equal(sg[k], ref[1])
+        np.testing.assert_array_equal(th[k], ref[2])
+        np.testing.assert_array_equal(d.leapfrogs_taken[k], ref[3])
+    eng.close()
