@@ -165,6 +165,7 @@ def main():
     t0 = time.perf_counter()
     lf, dev_ms = eng.sampler_run(a.steps)
     torch.cuda.synchronize()
+    own_s = time.perf_counter() - t0                     # this rank's own K transitions (the job's time is the slowest rank's)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -176,6 +177,12 @@ def main():
         dist.all_reduce(lfs, op=dist.ReduceOp.SUM)
     elapsed = float(tmax.item())
     lf_total = float(lfs.item())
+    per_rank = [[own_s * 1e3, float(lf)]]
+    if world > 1:                                         # every rank's own time and leapfrog count: NUTS chains build trees of different sizes,
+        mine = torch.tensor([own_s * 1e3, float(lf)], dtype=torch.float64, device=red_dev)      # and K transitions per chain is the protocol
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(x[0].item()), float(x[1].item())] for x in allr]
 
     # ---- final sample gather over RCCL (the only collective of the job) -------------------------------
     Xs, sp, tp = eng.sampler_samples()
@@ -345,6 +352,11 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu,
         "leapfrogs_per_s": round(lf_total / elapsed, 1),
         "leapfrogs_per_s_per_gpu": round(lf_total / elapsed / world, 1),
+        "per_rank_ms": [round(x[0], 2) for x in per_rank], "per_rank_leapfrogs": [int(x[1]) for x in per_rank],
+        "rank_balance": round(float(np.mean([x[0] for x in per_rank]) / max(x[0] for x in per_rank)), 4),
+        "rank_balance_note": "mean / max of the ranks' own times for their K NUTS transitions: chains build trees of different sizes (different leapfrog counts per "
+                             "rank above), the job ends with the slowest chain, and there is no communication inside the timed region -- this ratio, not the "
+                             "interconnect, is what an N-GPU efficiency below 1 consists of (fixed-L HMC, hmc_L32, has no such spread)",
         "us_per_leapfrog_slot": round(elapsed / (lf_total / n_chains) * 1e6, 2),
         "us_per_slot_issued": round(elapsed / max(slots_issued, 1) * 1e6, 3), "slots_issued_rank0": int(slots_issued),
         "slot_overhead_rank0": round(slots_issued / max(float(diag.leapfrogs_taken[:, a.burnin + a.warmup:a.burnin + a.warmup + a.steps].sum(axis=1).max()), 1.0), 4),
