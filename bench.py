@@ -63,6 +63,10 @@ def parse():
                          "BASELINE config 3 asks -- so the max-over-ranks time includes the NUTS tree-size spread between chains")
     ap.add_argument("--cpu-threads", type=str, default="1,8,32,all", help="thread counts of the torch-CPU baseline leg")
     ap.add_argument("--profile-slots", type=int, default=512, help="leapfrog slots of the in-sampler kernel-duration leg")
+    ap.add_argument("--config", choices=["headline", "alpha-sweep"], default="headline",
+                    help="headline: BASELINE configs[1] / configs[2] (see --chains-per-gpu).  alpha-sweep: BASELINE configs[3] -- the ten alpha-sweep "
+                         "datasets x 8 chains = 80 (dataset, chain) units dealt to the GPUs by whole datasets (magi_v2_amd/sweep.py), total work fixed: "
+                         "python -m torch.distributed.run ... bench.py --gpus 8 --config alpha-sweep")
     return ap.parse_args()
 
 
@@ -105,6 +109,82 @@ def cpu_gradient_rates(pb, mats, band, drift, P, state, threads, max_seconds):
     return pr, torch_cpu.time_gradients(pr, Xc, spc, tpc, threads, min_evals=200, max_seconds=max_seconds)
 
 
+def alpha_sweep_bench(a, rank, world, dev_index, red_dev):
+    """BASELINE configs[3]: 10 datasets (alpha = 0.05 / 0.15, seeds 0-4; tests/golden/seir_alpha_sweep.npz holds the vignette thinning of the
+    reference's data/*.csv) x 8 chains, N = 161, b = 80, reference defaults (stale cache as the reference).  Whole datasets are dealt to the
+    ranks, each rank builds its datasets' matrices on its GPU (untimed set-up, one handle per dataset), the timed region is exactly K
+    transitions of every chain, the samples of all 80 units are gathered once to rank 0.  Total work is fixed: "scaling": "strong"."""
+    from magi_v2_amd.sweep import SweepRunner, alpha_sweep_datasets
+    cpd = 8
+    datasets = alpha_sweep_datasets(os.path.join(ROOT, "tests", "golden", "seir_alpha_sweep.npz"))
+    if world > len(datasets):
+        raise SystemExit("alpha-sweep: at most one rank per dataset")
+    t0 = time.perf_counter()
+    run = SweepRunner(dev_index, datasets, cpd, rank, world, bandsize=80)
+    build_ms = (time.perf_counter() - t0) * 1e3
+    run.init(a.seed, num_results=a.warmup + a.steps, num_burnin_steps=a.burnin)
+    run.run(a.burnin)
+    if a.warmup > 0:
+        run.run(a.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lf = run.run(a.steps)
+    torch.cuda.synchronize()
+    own_s = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    lfs = torch.tensor([float(lf)], dtype=torch.float64, device=red_dev)
+    mine = torch.tensor([own_s * 1e3, float(lf), float(len(run.unit_ids))], dtype=torch.float64, device=red_dev)
+    allr = [mine]
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lfs, op=dist.ReduceOp.SUM)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+    elapsed, lf_total = float(tmax.item()), float(lfs.item())
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    allsamp, gids = run.gather(dst=0)
+    torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - t1) * 1e3 if world > 1 else 0.0
+    kernel = run.engines[0].stream_kernel_name(cpd)
+    names = [n for n, _ in datasets]
+    run.close()
+    if rank != 0:
+        return
+    units = len(datasets) * cpd
+    P = 3
+    th = np.log1p(np.exp(allsamp[:, a.warmup:, -P:]))                        # [units, steps, P]
+    per_ds = th.reshape(len(datasets), cpd * a.steps, P).mean(axis=1)
+    out = {
+        "metric": "HMC samples/sec (whole node) on SEIR, N grid pts x D comps",
+        "value": round(units * a.steps / elapsed, 4), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "reference data files (vignette thinning of data/SEIR_*alpha=*_seed=*.csv, tests/golden/seir_alpha_sweep.npz)",
+        "config": {"workload": f"SEIR alpha-sweep: {len(datasets)} datasets (alpha=0.05/0.15, seeds 0-4) x {cpd} chains, N=161 x 4 components, band 80, "
+                               "NUTS(max depth 10)+dual averaging+log annealing, reference defaults",
+                   "baseline_config": "BASELINE configs[3] (alpha-sweep: 10 datasets x 8 chains sharded by dataset)",
+                   "units_total": units, "datasets": names, "chains_per_dataset": cpd, "burnin_untimed": a.burnin,
+                   "parallelism": f"datasets x{world} (whole datasets per GPU, round-robin; one handle per dataset, a rank's datasets run concurrently)",
+                   "stale_cache": 1, "kernel": kernel},
+        "leapfrogs_per_s": round(lf_total / elapsed, 1),
+        "per_rank_ms": [round(float(x[0].item()), 2) for x in allr], "per_rank_leapfrogs": [int(x[1].item()) for x in allr],
+        "per_rank_units": [int(x[2].item()) for x in allr],
+        "rank_balance": round(float(np.mean([x[0].item() for x in allr]) / max(x[0].item() for x in allr)), 4),
+        "gathered_unit_ids": [int(g_) for g_ in gids], "gather_ms": round(gather_ms, 3), "build_ms_rank0": round(build_ms, 1),
+        "theta_mean_per_dataset": [[round(float(x), 4) for x in row] for row in per_ds],
+        "theta_last_per_unit": [[round(float(x), 10) for x in th[u, -1]] for u in range(units)],
+        "roofline": None, "cpu_baseline": None,
+        "note": "secondary configuration of bench.py (the driver's N = 1 line is --config headline, which carries roofline and cpu_baseline; "
+                "its cfg4_* scalars time one dataset of this sweep on one GPU)",
+    }
+    print(json.dumps(out))
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -124,6 +204,12 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     red_dev = "cpu" if rehearse else "cuda"
+
+    if a.config == "alpha-sweep":
+        alpha_sweep_bench(a, rank, world, dev_index, red_dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from magi_v2_amd import host
     from magi_v2_amd.engine import MagiEngine
@@ -226,12 +312,15 @@ def main():
            "accept_rate": round(float(hd.is_accepted[:, 100:].mean()), 3), "step_size": float(hd.step_size[0, -1]), "scope": "rank 0"}
 
     # ---- roofline of the dominant kernel (the streaming kernel) -------------------------------------------------
-    # `achieved` / `frac`: SURVEY 8d's ALGORITHMIC bytes of one gradient evaluation (3 D N W 8 + C 10 N D 8) over the kernel's
-    # mean IN-SAMPLER launch duration (st_us above; profiles/ holds the rocprofv3 kernel trace of this command, whose mean for
-    # the same kernel must agree).  The kernel itself streams fewer bytes -- the symmetric operators FH and FK are stored as
-    # their lower block triangle and FE serves both FE xc and FE^T f, about 2 N^2 D values instead of 3 (bytes_per_launch) --
-    # which is why `frac` can approach or exceed 1; frac_bytes_moved prices the bytes actually moved against the same peak,
-    # frac_of_ceiling against a load-only pass over the same blocks timed in this run; slot_frac is the per-leapfrog view.
+    # `achieved` / `frac`: the bytes the kernel MOVES per launch (magi_gradient_bytes: the packed operator blocks + what it stores;
+    # the PMC passes of profiles/ count the same bytes at the memory side -- `traffic`) over the kernel's mean IN-SAMPLER launch
+    # duration (st_us above; profiles/ holds the rocprofv3 kernel trace of this command, whose mean for the same kernel must
+    # agree), against the 8 TB/s HBM peak.  SURVEY 8d's ALGORITHMIC byte count of one gradient evaluation (3 D N W 8 + C 10 N D 8)
+    # is a third larger than what this formulation must move -- the symmetric operators FH and FK are stored as their lower block
+    # triangle and FE serves both FE xc and FE^T f -- so the fraction on that count (`frac_contract_bytes`, rounds 1-3's `frac`) can
+    # exceed 1 and is reported next to it, not as the kernel's fraction of the peak.  frac_of_ceiling prices the kernel against a
+    # load-only pass over the same blocks timed in this run; slot_frac_of_load_only = that pass over the whole leapfrog slot
+    # [stream, point] as the sampler ran it -- the number the per-leapfrog work is actually chasing.
     grad_ms, phase_ms = eng.time_gradient(cpg, 300)
     phase_bytes = eng.gradient_bytes(cpg)
     W = N if band is None or 6 * band + 1 >= N else 2 * band + 1
@@ -239,26 +328,32 @@ def main():
     t_stream = st_us * 1e-6
     t_alone = phase_ms[4] * 1e-3
     slot_s = elapsed / max(slots_issued, 1) if world == 1 else elapsed / (lf_total / n_chains)
-    n_tasks = phase_bytes[4] / (128 * 128 * 8.0 + 2.0 * cpg * 128 * 8.0)     # packed 128 x 128 blocks (magi_gradient_bytes)
+    n_tasks = eng.gradient_bytes(1)[4] / (128 * 128 * 8.0 + 2.0 * 128 * 8.0)     # packed 128 x 128 blocks (magi_gradient_bytes, one chain: blocks + 2 x 128 partials each)
     tiles_bytes = n_tasks * 128 * 128 * 8.0
     ceiling = tiles_bytes / (phase_ms[7] * 1e-3) / 1e9
     roofline = {"bound": "hbm",
-                "kernel": ("k_stream" if cpg <= 2 else "k_stream_mc") + " (single-phase block mat-vecs FH xc, FE xc, FE^T f, FK f over packed 128x128 blocks)",
-                "achieved": round(algorithmic / t_stream / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(algorithmic / t_stream / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
-                "frac_basis": "SURVEY 8d algorithmic bytes / mean in-sampler launch duration of the kernel (HIP events on every launch over "
-                              f"{a.profile_slots} slots of the timed chains)",
+                "kernel": eng.stream_kernel_name(cpg) + " (single-phase block mat-vecs FH xc, FE xc, FE^T f, FK f over packed 128x128 blocks)",
+                "achieved": round(phase_bytes[4] / t_stream / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(phase_bytes[4] / t_stream / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac_basis": "bytes the kernel moves per launch (operator blocks + stores; = the PMC traffic of profiles/) / mean in-sampler launch "
+                              f"duration of the kernel (HIP events on every launch over {a.profile_slots} slots of the timed chains) / HBM peak",
                 "us_per_launch": round(st_us, 3), "us_per_launch_point": round(pt_us, 3),
                 "algorithmic_bytes_per_launch": algorithmic, "bytes_per_launch": phase_bytes[4],
+                "achieved_contract_bytes": round(algorithmic / t_stream / 1e9, 1),
+                "frac_contract_bytes": round(algorithmic / t_stream / 1e9 / HBM_PEAK_GBPS, 4),
+                "frac_contract_note": "SURVEY 8d's algorithmic bytes (three full N x N stacks per component) over the same time: the kernel moves 0.72 of "
+                                      "them (symmetric block storage), so this ratio is not a fraction of the peak and may exceed 1",
                 "streamed_GBps": round(phase_bytes[4] / t_stream / 1e9, 1),
                 "frac_bytes_moved": round(phase_bytes[4] / t_stream / 1e9 / HBM_PEAK_GBPS, 4),
                 "ceiling_GBps": round(ceiling, 1),
                 "frac_of_ceiling": round((phase_bytes[4] / t_stream / 1e9) / ceiling, 4),
+                "slot_frac_of_load_only": round(phase_ms[7] * 1e-3 / slot_s, 4),
                 "slot_frac": round(algorithmic / slot_s / 1e9 / HBM_PEAK_GBPS, 4),
                 "slot_frac_bytes_moved": round((phase_bytes[4] + phase_bytes[6]) / slot_s / 1e9 / HBM_PEAK_GBPS, 4),
-                # the same kernel launched back to back WITHOUT its decision workgroups (round-1/2 definition of `frac`)
+                # the same kernel launched back to back WITHOUT its decision workgroups (round-1/2 definition)
                 "standalone_us_per_launch": round(phase_ms[4] * 1e3, 3),
-                "standalone_frac": round(algorithmic / t_alone / 1e9 / HBM_PEAK_GBPS, 4),
+                "standalone_frac": round(phase_bytes[4] / t_alone / 1e9 / HBM_PEAK_GBPS, 4),
+                "standalone_frac_contract_bytes": round(algorithmic / t_alone / 1e9 / HBM_PEAK_GBPS, 4),
                 "standalone_point_us": round(phase_ms[6] * 1e3, 3), "read_only_us": round(phase_ms[7] * 1e3, 3),
                 "three_phase_gradient_eval_us": round(grad_ms * 1e3, 3),
                 "working_set_MB": round(phase_bytes[4] / 1e6, 1),
@@ -271,7 +366,8 @@ def main():
         import csv
         if N == 1024 and cpg == 1 and (band is None or 6 * band + 1 >= N):
             prof = os.path.join(ROOT, "profiles")
-            name = next(f for f in ("r03_bench_pmc_traffic.csv", "r02_bench_pmc_traffic.csv", "r01_bench_pmc_traffic.csv") if os.path.exists(os.path.join(prof, f)))
+            name = next(f for f in ("r04_bench_pmc_traffic.csv", "r03_bench_pmc_traffic.csv", "r02_bench_pmc_traffic.csv", "r01_bench_pmc_traffic.csv")
+                        if os.path.exists(os.path.join(prof, f)))
             with open(os.path.join(prof, name)) as fh:
                 tr = sum(float(r["bytes_per_launch_corrected"]) for r in csv.DictReader(fh) if "k_stream<1, 1>" in r["Kernel_Name"])
             if tr > 0:
@@ -398,12 +494,16 @@ def extra_configs(a, eng, host, MagiEngine, pb2, roofline, threads, dev_index):
         "mc8_samples_per_s": round(8 * steps3 / el, 2), "mc8_leapfrogs_per_s": round(lf3 / el, 1),
         "mc8_us_per_slot": round(el / max(slots, 1) * 1e6, 3), "mc8_slots_issued": int(slots),
         "mc8_stream_us": round(st_us, 3), "mc8_point_us": round(pt_us, 3), "mc8_stream_us_standalone": round(ph8[4] * 1e3, 3),
-        "mc8_frac": round(alg8 / (st_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+        "mc8_kernel": eng.stream_kernel_name(8),
+        "mc8_frac": round(pbytes[4] / (st_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+        "mc8_bytes_per_launch": pbytes[4], "mc8_point_bytes_per_launch": pbytes[6],
+        "mc8_frac_contract_bytes": round(alg8 / (st_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
         "mc8_frac_bytes_moved": round(pbytes[4] / (st_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
         "mc8_frac_of_ceiling": round(ph8[7] * 1e3 / st_us, 4),
+        "mc8_slot_frac_of_load_only": round(ph8[7] * 1e-3 / (el / max(slots, 1)), 4),
         "mc8_mfma_frac": round(8 * 8.0 * D * 1024 * 1024 / (st_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
         "mc8_timed_transitions": steps3})
-    note["config3_share"] = f"8 chains (ids 0..7), N=1024 x 4 dense, {a.burnin} untimed burn-in + 3 warm-up, {steps3} timed NUTS transitions; k_stream_mc durations from {a.profile_slots} event-timed slots"
+    note["config3_share"] = f"8 chains (ids 0..7), N=1024 x 4 dense, {a.burnin} untimed burn-in + 3 warm-up, {steps3} timed NUTS transitions; {eng.stream_kernel_name(8)} durations from {a.profile_slots} event-timed slots"
 
     # ---- config 1: SEIR-4, N = 161 (81 thinned rows of data/SEIR_seed=0.csv, discretization 1), b = 80, 1 chain, 200 + 200 ----
     g3 = np.load(os.path.join(ROOT, "tests", "golden", "g3_pipeline.npz"))
@@ -450,12 +550,10 @@ def extra_configs(a, eng, host, MagiEngine, pb2, roofline, threads, dev_index):
     tb = time.perf_counter()
     e5.build_matrices(I5, pb5["hp"]["phi1s"], pb5["hp"]["phi2s"], 2.01, want_host=False)
     build_s = time.perf_counter() - tb
-    os.environ["MAGI_BUILD_PROFILE"] = "1"
-    try:
-        e5.build_matrices(I5, pb5["hp"]["phi1s"], pb5["hp"]["phi2s"], 2.01, want_host=False)
-        prof = e5.build_profile()
-    finally:
-        del os.environ["MAGI_BUILD_PROFILE"]
+    e5.set_option("build_profile", 1)
+    e5.build_matrices(I5, pb5["hp"]["phi1s"], pb5["hp"]["phi2s"], 2.01, want_host=False)
+    prof = e5.build_profile()
+    e5.set_option("build_profile", 0)
     fl = lambda k: prof[k][0]
     ms = lambda k: prof[k][1]
     potrf_ms = ms("diag_chol_inv") + ms("potrf_panel") + ms("potrf_trailing_syrk")

@@ -205,7 +205,9 @@ int magi_sampler_get_state(magi_handle* h, double* X, double* sig_pre, double* t
  * and chain_ids and the checkpointed states, then magi_sampler_set_checkpoint(scalars), then magi_sampler_run: the remaining
  * transitions are those the uninterrupted run would have made, bit for bit (the Philox streams are keyed by transition index
  * and chain id; target and gradient of the restored state are re-evaluated by the same kernels).  Samples and diagnostics of
- * the steps taken before the checkpoint belong to the run that took them. */
+ * the steps taken before the checkpoint belong to the run that took them.  The scalars carry a tag of (cfg, seed, chain id,
+ * state size): magi_sampler_set_checkpoint rejects (MAGI_E_BADARG) a checkpoint taken under anything else, and any scalar that
+ * is not finite / not a whole number where one is expected / outside its range. */
 #define MAGI_CKPT_SCALARS 16
 int magi_sampler_get_checkpoint(magi_handle* h, double* scalars /* [n_chains][MAGI_CKPT_SCALARS] */);
 int magi_sampler_set_checkpoint(magi_handle* h, const double* scalars /* [n_chains][MAGI_CKPT_SCALARS] */);
@@ -240,12 +242,26 @@ int magi_sampler_run_stats(magi_handle* h, int64_t* slots_issued, int64_t* graph
 int magi_sampler_profile(magi_handle* h, int n_slots, double* stream_us, double* point_us, int64_t* leapfrogs_done);
 
 /* phase_bytes[8]: bytes each of those seven kernels must move per launch for the current matrices
- * and n_chains; [7] = the algorithmic bytes of one gradient evaluation as
- * SURVEY 8d counts them (3 D N W 8 + C 10 N D 8). */
+ * and n_chains, for the kernel family that serves a batch of n_chains (magi_stream_kernel_name):
+ * [4] = the streaming kernel: packed operator blocks + what it stores (+ for k_stream_sep its operand planes, once per XCD);
+ * [6] = k_point; [7] = the algorithmic bytes of one gradient evaluation as SURVEY 8d counts them (3 D N W 8 + C 10 N D 8). */
 int magi_gradient_bytes(magi_handle* h, int n_chains, double* phase_bytes);
 
-/* Diagnostics: per-class device time of the last magi_build_matrices when the environment variable
- * MAGI_BUILD_PROFILE is set (HIP events around every launch; the build is serialised while profiling).
+/* Name of the streaming kernel a batch of n_chains runs on with the current matrices, problem and options:
+ * "k_stream<1>", "k_stream<2>" (VALU), "k_stream_sep<CW=8|16>" (matrix cores, separable drift), "k_stream_mc". */
+int magi_stream_kernel_name(magi_handle* h, int n_chains, char* buf, int cap);
+
+/* Tuning / test switches of a handle (csrc/magi_internal.h: MagiOptions).  The environment variables MAGI_STREAM_FAMILY,
+ * MAGI_SEP_PAIR_MIN, MAGI_FUSED_PARITY, MAGI_GEMM_REMAP_MIN, MAGI_POTRF_PANELS, MAGI_NO_GRAPH, MAGI_FIT_HOST_LOOP,
+ * MAGI_FIT_PER_COMPONENT, MAGI_BUILD_PROFILE, MAGI_BUILD_SERIAL are read ONCE, by magi_create; afterwards only this call
+ * changes an option (no getenv on a compute path).  Names: "stream_family" (0 auto, 1 mc, 2 valu; takes effect at the next
+ * magi_sampler_init / log-posterior call), "sep_pair_min" (next packing), "fused_parity", "gemm_remap_min", "potrf_panels",
+ * "no_graph", "fit_host_loop", "fit_per_component", "build_profile", "build_serial", and the test hook
+ * "slot_budget_graphs" (cap on the graph launches of one magi_sampler_run; 0 = the computed bound; no environment variable). */
+int magi_set_option(magi_handle* h, const char* name, int64_t value);
+
+/* Diagnostics: per-class device time of the last magi_build_matrices run with option "build_profile" set
+ * (HIP events around every launch; the build is serialised while profiling).
  * Classes, in order: matern, diag-block Cholesky+inverse, potrf panel, potrf trailing SYRK, trtri,
  * T^T T, m / K products, single-phase operators.  flops = fp64 operations actually issued.  Returns the
  * number of classes (8); arrays must hold at least that many entries. */

@@ -890,10 +890,8 @@ int launch_gemm(magi_handle* h, hipStream_t s, const GemmArgs& g_in, int batch =
     if (g.M <= 0 || g.N <= 0 || batch <= 0) return MAGI_OK;
     const int tY = (g.M + GT - 1) / GT, tX = (g.N + GT - 1) / GT, sY = (tY + 7) / 8, sX = (tX + 7) / 8;
     const int nsuper = g.lower_only ? sY * (sY + 1) / 2 : sY * sX;           // (lower-only: square tile grids)
-    // (read at every launch, not cached: tests/test_fullsize_gpu.py forces the super-block order on small tile grids with
-    //  MAGI_GEMM_REMAP_MIN=1 in the same process that later runs the default)
-    const char* remap_env = getenv("MAGI_GEMM_REMAP_MIN");
-    const int remap_min = remap_env ? atoi(remap_env) : 24;
+    // (an option of the handle: tests/test_fullsize_gpu.py forces the super-block order on small tile grids with gemm_remap_min = 1)
+    const int remap_min = h->opt.gemm_remap_min;
     g.remap = (nsuper >= remap_min && (!g.lower_only || tY == tX)) ? 1 : 0;
     dim3 grid(g.remap ? ((nsuper + 7) / 8) * 8 * 64 : tY * tX, 1, batch);
     prof_begin(s);
@@ -971,8 +969,7 @@ int potrf(Linalg& la, double* A, const char* what, bool defer_status = false, in
     // (Look-ahead -- the rest of a trailing update on a second stream under the next block column's diagonal / panel chain -- was
     //  measured: 347 against 345 ms at N = 8192.  The update's workgroups hold every CU's LDS, and the diagonal kernel needs 158 KB
     //  of one CU: it does not start before the update drains.)
-    const char* npan_env = getenv("MAGI_POTRF_PANELS");
-    const int NPAN = std::max(1, std::min(npan_env ? atoi(npan_env) : 4, 16));
+    const int NPAN = std::max(1, std::min(h->opt.potrf_panels, 16));
     int rc = MAGI_OK;
     for (int j0 = 0; j0 < N && rc == MAGI_OK; j0 += NPAN * NB) {
         for (int c = 0; c < NPAN && rc == MAGI_OK; ++c) {
@@ -1229,7 +1226,7 @@ int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const
             if (w.stream) (void)hipStreamDestroy(w.stream);
         }
     };
-    const bool batched_fit = !getenv("MAGI_FIT_HOST_LOOP") && !getenv("MAGI_FIT_PER_COMPONENT") && D <= 8;
+    const bool batched_fit = !h->opt.fit_host_loop && !h->opt.fit_per_component && D <= 8;
     for (int d = 0; d < D && rc == MAGI_OK && !batched_fit; ++d) {
         FitWork& w = ws[d];
         w.N = N;
@@ -1356,7 +1353,7 @@ int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const
         for (int d = 0; d < D; ++d) { phi1[d] = softplus(raw[d]); phi2[d] = softplus(raw[D + d]); sig2[d] = softplus(raw[2 * D + d]); }
         return MAGI_OK;
     }
-    if (!getenv("MAGI_FIT_HOST_LOOP")) {
+    if (!h->opt.fit_host_loop) {
         // Device-resident loop: one Adam step of one component = one captured graph (Matern blocks -> Cholesky -> inverse ->
         // reductions -> k_fit_step) whose inputs live in the component's FitDyn block; the host replays it `iters` times on
         // the component's stream and synchronises once at the end.
@@ -1504,7 +1501,7 @@ int magi_ensure_dense(magi_handle* h, int N, int D) {
 // Eqn. 6 matrices of the components sel[0 .. n_sel) (phi1 / phi2 indexed like sel) into the handle's dense stacks
 int magi_build_dense_device(magi_handle* h, const double* I, int N, int D, int n_sel, const int* sel, const double* phi1, const double* phi2,
                             double nu) {
-    g_prof.on = getenv("MAGI_BUILD_PROFILE") != nullptr;
+    g_prof.on = h->opt.build_profile != 0;
     if (g_prof.on) {
         if (!g_prof.e0) { (void)hipEventCreate(&g_prof.e0); (void)hipEventCreate(&g_prof.e1); }
         for (int i = 0; i < BC_COUNT; ++i) { g_prof.flops[i] = 0.0; g_prof.ms[i] = 0.0; g_prof.calls[i] = 0; }
@@ -1530,7 +1527,7 @@ int magi_build_dense_device(magi_handle* h, const double* I, int N, int D, int n
         const size_t per = (3 * nn + std::max((size_t)N * 128, nn / 2 + 128 * 128) + (size_t)((N + 127) / 128) * 128 * 128) * sizeof(double);
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
             B = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_sel, (free_b / 10 * 9) / per));
-        if (getenv("MAGI_BUILD_SERIAL")) B = 1;
+        if (h->opt.build_serial) B = 1;
     }
     struct { double* p; } Kap{magi_workspace(h, magi_handle::WS_KAP, nn * B)}, P{magi_workspace(h, magi_handle::WS_P, nn * B)},
         PP{magi_workspace(h, magi_handle::WS_PP, nn * B)};

@@ -108,6 +108,21 @@ int build_graph(magi_handle* h) {
 
 }  // namespace
 
+void magi_options_from_env(MagiOptions& o) {
+    auto num = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; };
+    if (const char* e = getenv("MAGI_STREAM_FAMILY")) o.stream_family = std::string(e) == "mc" ? 1 : std::string(e) == "valu" ? 2 : 0;
+    o.sep_pair_min = (int)num("MAGI_SEP_PAIR_MIN", o.sep_pair_min);
+    o.fused_parity = num("MAGI_FUSED_PARITY", 0) == 1;
+    o.gemm_remap_min = (int)num("MAGI_GEMM_REMAP_MIN", o.gemm_remap_min);
+    o.potrf_panels = (int)num("MAGI_POTRF_PANELS", o.potrf_panels);
+    o.no_graph = getenv("MAGI_NO_GRAPH") != nullptr;
+    o.fit_host_loop = getenv("MAGI_FIT_HOST_LOOP") != nullptr;
+    o.fit_per_component = getenv("MAGI_FIT_PER_COMPONENT") != nullptr;
+    o.build_profile = getenv("MAGI_BUILD_PROFILE") != nullptr;
+    o.build_serial = getenv("MAGI_BUILD_SERIAL") != nullptr;
+    // (slot_budget_graphs has no variable: a test hook must not be reachable from a job's environment)
+}
+
 double* magi_workspace(magi_handle* h, int k, size_t n) {
     if (n <= h->ws_cap[k]) return h->ws[k];
     if (h->ws[k]) (void)hipFree(h->ws[k]);
@@ -155,7 +170,7 @@ int magi_ensure_chains(magi_handle* h, int n) {
         MAGI_HIP_CHECK(h, hipMalloc(&h->d_fin, sizeof(double) * 8 * n));
         h->cap_chains = n;
     }
-    const bool fam = magi_stream_family_mc(n, h->pb.n_tasks);
+    const bool fam = magi_stream_family_mc(h, n);
     if (h->n_chains != n || fam != h->family_mc) drop_graph(h);
     if (h->n_chains != n && h->ch.vop)       // the mirror's layout depends on the chain count: entries the new layout never writes must read zero
         MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.vop, 0, sizeof(double) * h->vop_elems, h->stream));
@@ -207,6 +222,7 @@ magi_handle* magi_create(int device_id) {
     }
     magi_handle* h = new magi_handle();
     h->device = device_id;
+    magi_options_from_env(h->opt);
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipHostMalloc((void**)&h->h_gctl, sizeof(GlobalCtl) * 4, hipHostMallocDefault)) != hipSuccess) {
         g_magi_last_error = std::string("handle setup: ") + hipGetErrorString(e);
@@ -406,10 +422,9 @@ static int logpost_grad_impl(magi_handle* h, bool fused, int n_chains, const dou
     MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.gctl, 0, sizeof(GlobalCtl), h->stream));
     if ((rc = magi_launch_prepare(h, n_chains, h->stream))) return rc;
     if (fused) {
-        // (MAGI_FUSED_PARITY=1: evaluate as an ODD leapfrog slot does -- the streaming kernels walk their blocks backwards there and
+        // (option fused_parity = 1: evaluate as an ODD leapfrog slot does -- the streaming kernels walk their blocks backwards there and
         //  read the other halves of the plan ring and of the operand mirrors; tests compare the two)
-        const char* pe = getenv("MAGI_FUSED_PARITY");
-        const int par = (pe && atoi(pe) == 1) ? 1 : 0;
+        const int par = h->opt.fused_parity ? 1 : 0;
         if ((rc = magi_launch_plan_eval(h, n_chains, h->stream, par))) return rc;
         if ((rc = magi_launch_stream(h, n_chains, par, false, h->stream))) return rc;
         if ((rc = magi_launch_point(h, n_chains, par, h->stream))) return rc;
@@ -555,9 +570,9 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
     if (n_steps <= 0) return magi_fail(h, MAGI_E_BADARG, "n_steps must be positive");
     (void)hipSetDevice(h->device);
     int rc;
-    // MAGI_NO_GRAPH=1: launch the leapfrog slots directly (debugging / rocprofv3 kernel traces of
+    // option no_graph (MAGI_NO_GRAPH=1 at handle creation): launch the leapfrog slots directly (debugging / rocprofv3 kernel traces of
     // long runs: the profiler's graph-node bookkeeping does not survive ~10^5 replayed nodes)
-    const bool use_graph = getenv("MAGI_NO_GRAPH") == nullptr;
+    const bool use_graph = !h->opt.no_graph;
     if (use_graph && !h->graph_valid && (rc = build_graph(h))) return rc;
 
     std::vector<ChainCtl> ctl(h->n_chains);
@@ -585,7 +600,7 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
     // (+ one more set-up slot per doubling and two per transition end when a batch of NUTS chains spreads those passes: decide.h)
     const long long per_transition = (h->cfg.mode == MAGI_MODE_HMC ? (long long)h->cfg.hmc_L : (1ll << (h->cfg.max_depth + 1))) + 2 * h->cfg.max_depth + 8;
     long long max_graphs = ((long long)(g.stop_k - kmin) * per_transition + 8) / kGraphSlots + 4;
-    if (const char* e = getenv("MAGI_SLOT_BUDGET_GRAPHS")) max_graphs = std::max(1ll, std::min(max_graphs, (long long)atoll(e)));    // (tests: force the budget exit)
+    if (h->opt.slot_budget_graphs > 0) max_graphs = std::max(1ll, std::min(max_graphs, h->opt.slot_budget_graphs));    // (test hook, magi_set_option only: force the budget exit)
     while (!done) {
         if (issued >= max_graphs && issued == retired) {
             (void)hipStreamSynchronize(h->stream);
@@ -758,7 +773,19 @@ int magi_sampler_get_state(magi_handle* h, double* X, double* sig_pre, double* t
 }
 
 // per-chain scalars of a checkpoint (magi_sampler_get_checkpoint / magi_sampler_set_checkpoint)
-enum { CKPT_K = 0, CKPT_DA_STEP, CKPT_STEP_SIZE, CKPT_ERR_SUM, CKPT_LOG_AVG, CKPT_LOG_SHRINK, CKPT_BETA_CACHE, CKPT_TOTAL_LF, CKPT_COUNT };
+enum { CKPT_K = 0, CKPT_DA_STEP, CKPT_STEP_SIZE, CKPT_ERR_SUM, CKPT_LOG_AVG, CKPT_LOG_SHRINK, CKPT_BETA_CACHE, CKPT_TOTAL_LF, CKPT_TAG, CKPT_COUNT };
+
+// What a checkpoint belongs to: the sampler configuration, the seed, the chain's Philox id and the state size, folded into 52 bits (exact in a
+// double).  A resume promises the uninterrupted run bit for bit, which only holds under the same configuration: set_checkpoint compares.
+static double ckpt_tag(const magi_handle* h, long long chain_id) {
+    unsigned long long x = 1469598103934665603ull;
+    auto mix = [&x](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { x ^= b[i]; x *= 1099511628211ull; } };
+    const SamplerCfgDev& c = h->cfg;
+    const int ints[9] = {c.total, c.burnin, c.n_adapt, c.max_depth, c.mode, c.mode == MAGI_MODE_HMC ? c.hmc_L : 0, c.anneal, c.stale, h->pb.dimp};
+    const double dbl[4] = {c.step_size, c.target_accept, c.max_energy_diff, c.min_temp};
+    mix(ints, sizeof(ints)); mix(dbl, sizeof(dbl)); mix(&c.seed, sizeof(c.seed)); mix(&chain_id, sizeof(chain_id));
+    return (double)(x & ((1ull << 52) - 1));
+}
 
 int magi_sampler_get_checkpoint(magi_handle* h, double* scalars) {
     if (!h || !scalars) return MAGI_E_BADARG;
@@ -773,6 +800,7 @@ int magi_sampler_get_checkpoint(magi_handle* h, double* scalars) {
         o[CKPT_K] = ctl[c].k; o[CKPT_DA_STEP] = ctl[c].da_step; o[CKPT_STEP_SIZE] = ctl[c].da_step_size;
         o[CKPT_ERR_SUM] = ctl[c].da_error_sum; o[CKPT_LOG_AVG] = ctl[c].da_log_avg; o[CKPT_LOG_SHRINK] = ctl[c].da_log_shrink;
         o[CKPT_BETA_CACHE] = ctl[c].beta_cache; o[CKPT_TOTAL_LF] = (double)ctl[c].total_leapfrogs;
+        o[CKPT_TAG] = ckpt_tag(h, ctl[c].chain_id);
     }
     return MAGI_OK;
 }
@@ -787,7 +815,16 @@ int magi_sampler_set_checkpoint(magi_handle* h, const double* scalars) {
     for (int c = 0; c < h->n_chains; ++c) {
         const double* o = scalars + (size_t)c * MAGI_CKPT_SCALARS;
         if (ctl[c].phase != PH_IDLE || ctl[c].k != 0) return magi_fail(h, MAGI_E_STATE, "set the checkpoint right after magi_sampler_init");
-        if (o[CKPT_K] < 0 || o[CKPT_K] > h->cfg.total || !(o[CKPT_STEP_SIZE] > 0.0)) return magi_fail(h, MAGI_E_BADARG, "checkpoint of chain " + std::to_string(c) + " does not fit this configuration");
+        auto whole = [](double v, double hi) { return std::isfinite(v) && v >= 0.0 && v <= hi && v == std::floor(v); };
+        const std::string who = "checkpoint of chain " + std::to_string(c);
+        if (!whole(o[CKPT_K], (double)h->cfg.total) || !whole(o[CKPT_DA_STEP], 2147483647.0) || !whole(o[CKPT_TOTAL_LF], 9007199254740992.0))
+            return magi_fail(h, MAGI_E_BADARG, who + ": transition index / adaptation step / leapfrog count must be whole numbers inside this configuration");
+        if (!(o[CKPT_STEP_SIZE] > 0.0) || !std::isfinite(o[CKPT_STEP_SIZE]) || !std::isfinite(o[CKPT_ERR_SUM]) || !std::isfinite(o[CKPT_LOG_AVG]) ||
+            !std::isfinite(o[CKPT_LOG_SHRINK]) || !(o[CKPT_BETA_CACHE] > 0.0) || !(o[CKPT_BETA_CACHE] <= 1.4426950408889636))      // (the schedule starts at 1 / ln 2, magi_v2.py:833-835)
+            return magi_fail(h, MAGI_E_BADARG, who + ": non-finite dual-averaging state, step size <= 0 or cached temperature outside (0, 1 / ln 2]");
+        if (o[CKPT_TAG] != ckpt_tag(h, ctl[c].chain_id))
+            return magi_fail(h, MAGI_E_BADARG, who + " was taken under another sampler configuration, seed, chain id or problem size: a resume continues "
+                                               "the SAME run (magi_hip.h)");
         ctl[c].k = (int)o[CKPT_K]; ctl[c].da_step = (int)o[CKPT_DA_STEP]; ctl[c].da_step_size = o[CKPT_STEP_SIZE];
         ctl[c].da_error_sum = o[CKPT_ERR_SUM]; ctl[c].da_log_avg = o[CKPT_LOG_AVG]; ctl[c].da_log_shrink = o[CKPT_LOG_SHRINK];
         ctl[c].beta_cache = o[CKPT_BETA_CACHE]; ctl[c].total_leapfrogs = (long long)o[CKPT_TOTAL_LF];
@@ -819,6 +856,25 @@ int magi_fit_hparams(magi_handle* h, const double* I, int N, int D, const double
                                    phi1, phi2, sigma_sq, loss_trace);
 }
 
+int magi_set_option(magi_handle* h, const char* name, int64_t value) {
+    if (!h || !name) return MAGI_E_BADARG;
+    const std::string k(name);
+    MagiOptions& o = h->opt;
+    if (k == "stream_family") { if (value < 0 || value > 2) return magi_fail(h, MAGI_E_BADARG, "stream_family: 0 auto, 1 mc, 2 valu"); o.stream_family = (int)value; }
+    else if (k == "sep_pair_min") o.sep_pair_min = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
+    else if (k == "fused_parity") o.fused_parity = value == 1;
+    else if (k == "gemm_remap_min") o.gemm_remap_min = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
+    else if (k == "potrf_panels") { if (value < 1 || value > 16) return magi_fail(h, MAGI_E_BADARG, "potrf_panels in [1, 16]"); o.potrf_panels = (int)value; }
+    else if (k == "slot_budget_graphs") o.slot_budget_graphs = std::max<int64_t>(0, value);
+    else if (k == "no_graph") o.no_graph = value != 0;
+    else if (k == "fit_host_loop") o.fit_host_loop = value != 0;
+    else if (k == "fit_per_component") o.fit_per_component = value != 0;
+    else if (k == "build_profile") o.build_profile = value != 0;
+    else if (k == "build_serial") o.build_serial = value != 0;
+    else return magi_fail(h, MAGI_E_BADARG, "unknown option '" + k + "'");
+    return MAGI_OK;
+}
+
 int magi_build_profile(magi_handle* h, double* flops, double* ms, int64_t* calls) {
     if (!h || !flops || !ms || !calls) return MAGI_E_BADARG;
     long c[16];
@@ -846,10 +902,31 @@ int magi_gradient_bytes(magi_handle* h, int n_chains, double* phase_bytes) {
     phase_bytes[2] = 1.0 * mat + 5.0 * vec;   // Mt      ; read Kr, X, Cx, yobs, write gX
     phase_bytes[3] = 5.0 * vec;               // reduce  ; read X, Cx, r, Kr, yobs
     const double nslot = (double)std::min(pb.nb, 2 * pb.wb + 1);
-    phase_bytes[4] = (double)pb.n_tasks * MAGI_TB * MAGI_TB * 8.0 + 2.0 * (double)n_chains * pb.n_tasks * MAGI_TB * 8.0;   // k_stream: packed blocks of FH, FK (lower block triangle), FE; writes 2 TB partials per block and chain
+    const double tiles = (double)pb.n_tasks * MAGI_TB * MAGI_TB * 8.0;      // packed blocks of FH, FK (lower block triangle), FE
+    phase_bytes[4] = tiles + 2.0 * (double)n_chains * pb.n_tasks * MAGI_TB * 8.0;   // k_stream / k_stream_mc: + 2 TB partials per block and chain
     phase_bytes[5] = (double)n_chains * magi_leap_wgs(pb) * PART_K * 8.0; // tail: the workgroup partials
     phase_bytes[6] = 4.0 * vec * nslot + 10.0 * vec;                       // k_point: block partials of the four products; X, yobs, p, rho, g, p_leaf, p', x'
+    if (h->have_problem && magi_stream_family_mc(h, n_chains) && magi_drift_separable(pb.drift)) {
+        // k_stream_sep writes a block vector per (task, product, matrix-core column in use) and reads its operands from the mirror planes
+        // (once per XCD at the fabric); its point kernel re-reads the product slots and writes the next slot's mirror
+        double st = 0.0, op = 0.0, pr = 0.0, mw = 0.0;
+        magi_sep_traffic(pb, n_chains, &st, &op, &pr, &mw);
+        phase_bytes[4] = tiles + op + st;
+        phase_bytes[6] = pr + 10.0 * vec + mw;
+    }
     phase_bytes[7] = 3.0 * (double)pb.D * pb.N * W * 8.0 + 10.0 * vec;    // SURVEY 8d algorithmic bytes of one gradient evaluation
+    return MAGI_OK;
+}
+
+int magi_stream_kernel_name(magi_handle* h, int n_chains, char* buf, int cap) {
+    if (!h || !buf || cap < 2) return MAGI_E_BADARG;
+    if (!h->have_matrices || !h->have_problem) return magi_fail(h, MAGI_E_STATE, "set matrices and problem first");
+    std::string s;
+    if (magi_stream_family_mc(h, n_chains))
+        s = magi_drift_separable(h->pb.drift) ? (n_chains <= 8 ? "k_stream_sep<CW=8>" : "k_stream_sep<CW=16>") : "k_stream_mc";
+    else
+        s = n_chains >= 2 ? "k_stream<2>" : "k_stream<1>";
+    std::snprintf(buf, (size_t)cap, "%s", s.c_str());
     return MAGI_OK;
 }
 

@@ -15,6 +15,29 @@
 
 namespace {
 
+// dev (-DMAGI_WG_TRACE): begin / end (100 MHz real-time counter), hardware placement and a tag of EVERY workgroup of the last launch of
+// the streaming kernel [0] and of k_point [1] (tools/exp_wg_trace.py: where a launch's time goes across the grid)
+#ifdef MAGI_WG_TRACE
+__device__ unsigned long long g_wg_trace[2][4096][4];
+struct WgTrace {
+    int kern, wg;
+    __device__ __forceinline__ WgTrace(int kern_, int tag) : kern(kern_) {
+        wg = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+        if (threadIdx.x == 0 && wg < 4096) {
+            g_wg_trace[kern][wg][0] = __builtin_amdgcn_s_memrealtime();
+            g_wg_trace[kern][wg][2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+            g_wg_trace[kern][wg][3] = (unsigned long long)(long long)tag;
+        }
+    }
+    __device__ __forceinline__ ~WgTrace() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the workgroup's stores have retired)
+        if ((threadIdx.x & 63) == 0 && wg < 4096) atomicMax(&g_wg_trace[kern][wg][1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
+};
+#define WG_TRACE(kern, tag) WgTrace wg_trace_((kern), (tag))
+#else
+#define WG_TRACE(kern, tag) do { } while (0)
+#endif
 
 // Transposed butterfly: v[0..8) per lane -> every lane returns the 64-lane sum of v[lane >> 3].
 // Halving steps hand half of the values to the partner (v_permlane32/16_swap move both halves in one
@@ -79,6 +102,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) __attribute__((amdgpu_waves_per_eu(3
 void k_stream(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     using DR = DriftT<DRIFT>;
     constexpr int D = DR::D, P = DR::P, TB = MAGI_TB;
+    WG_TRACE(0, 0);
     // (the "all chains idle" flag is fetched here but tested after the other first loads are on the wire: an early return on it
     //  would put one more dependent round trip in front of every workgroup of every slot)
     const int all_done = ch.gctl->all_done;
@@ -348,6 +372,7 @@ void k_stream_mc(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     using DR = DriftT<DRIFT>;
     constexpr int D = DR::D, P = DR::P, TB = MAGI_TB;
     static_assert(P <= 8, "theta slots");
+    WG_TRACE(0, 0);
     const int all_done = ch.gctl->all_done;
     kernarg_prefetch<sizeof(DevProblem) + sizeof(DevChains) + sizeof(SamplerCfgDev) + sizeof(int)>();
     const int c0 = blockIdx.y * MC;
@@ -686,6 +711,7 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
 #define SEP_STAMP(i) do { } while (0)
 #endif
     SEP_STAMP(0);
+    WG_TRACE(0, 0);
     const int all_done = ch.gctl->all_done;
     kernarg_prefetch<sizeof(DevProblem) + sizeof(DevChains) + sizeof(SamplerCfgDev) + sizeof(int)>();
     const int c0 = blockIdx.y * MC, z = blockIdx.z;
@@ -713,6 +739,14 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     const int li = lane & 15, lj = lane >> 4;
     double* stage = smem + MC_SM_ST + wave * 16 * MC_PITCH;
     const int tix = (int)blockIdx.x - n_dec;
+#ifdef MAGI_SEP_STAGGER      // dev A/B: half of the workgroups enter MAGI_SEP_STAGGER x 64 cycles late (mode 0: odd tasks, 1: the second half of the grid)
+#ifndef MAGI_SEP_STAGGER_MODE
+#define MAGI_SEP_STAGGER_MODE 0
+#endif
+    if (MAGI_SEP_STAGGER_MODE == 0 ? (tix & 1) != 0 : tix >= pb.n_stasks / 2) {
+        for (int k_ = 0; k_ < (MAGI_SEP_STAGGER); k_ += 100) __builtin_amdgcn_s_sleep(100);
+    }
+#endif
     typedef const int __attribute__((address_space(4))) * const_int_ptr;
     const_int_ptr tk = (const_int_ptr)(unsigned long long)(pb.stasks + 8 * (size_t)tix);
     const int d = tk[0], bi = tk[2], bj = tk[3];
@@ -962,6 +996,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_point(DevProblem pb, DevChains c
     __shared__ double redk[64 * PART_K];
     __shared__ double s_mu[MAGI_MAX_D];
     __shared__ double s_x[PT_POINTS * PT_DSLOT];
+    WG_TRACE(1, 0);
     // (flag and plan are fetched together and combined arithmetically: `a || b` would fetch b only after a has arrived --
     //  one more dependent round trip at the head of a 5 us kernel)
     const int all_done = ch.gctl->all_done;
@@ -1074,17 +1109,17 @@ int launch_stream_mc(magi_handle* h, int n_chains, int parity, bool with_decisio
 // matrix-core kernel (k_stream_sep for separable drifts, k_stream_mc otherwise).  The two sum in different orders, so a chain's rounding depends on the size of the batch it
 // runs in (1-2 against >= 3).  MAGI_STREAM_FAMILY=mc routes EVERY batch size through the matrix-core kernel: a chain's samples
 // are then bit-identical whatever shares the GPU with it (uneven shards, e.g. 5 chains on 2 GPUs = 3 + 2), at the price of the
-// slower kernel for one or two chains.  Read at every sampler initialisation (magi_ensure_chains).
+// slower kernel for one or two chains.  (Option stream_family of the handle -- the variable is read when the handle is created, magi_set_option
+// afterwards -- evaluated at every magi_ensure_chains.)
 // Small problems stay on the VALU kernel whatever the batch: with about one workgroup per CU (blocks x chain pairs <= 320) a launch is
 // as long as its longest workgroup, and the matrix-core kernels' workgroups are long (prologue + 8 dependent steps + stores).  Slot time,
 // VALU against matrix-core kernel: N = 161, b = 80, 8 chains 12.9 / 16.0 us; N = 256, 8 chains 13.0 / 16.0; N = 512, 3 and 4 chains
 // (288 workgroups) 14.6 / 16.0 and 14.9 / 16.2; N = 512, 8 chains (576) 20.0 / 17.0; N = 1024, 3 chains 30.7 / 23.5.
-// MAGI_STREAM_FAMILY=valu forces the VALU kernel for every batch (A/B).
-bool magi_stream_family_mc(int n_chains, int n_tasks) {
-    const char* e = getenv("MAGI_STREAM_FAMILY");
-    if (e && std::string(e) == "mc") return true;
-    if (e && std::string(e) == "valu") return false;
-    return n_chains >= 3 && (long)n_tasks * ((n_chains + 1) / 2) > 320;
+// stream_family = valu forces the VALU kernel for every batch (A/B).
+bool magi_stream_family_mc(const magi_handle* h, int n_chains) {
+    if (h->opt.stream_family == 1) return true;
+    if (h->opt.stream_family == 2) return false;
+    return n_chains >= 3 && (long)h->pb.n_tasks * ((n_chains + 1) / 2) > 320;
 }
 
 bool magi_drift_separable(int drift) {
@@ -1113,6 +1148,44 @@ size_t magi_sep_vop_elems(const DevProblem& pb, int n_chains) {
     MAGI_DRIFT_DISPATCH(pb.drift, MAGI_CALL);
 #undef MAGI_CALL
     return 0;
+}
+
+// Memory-side byte model of one launch of the separable streaming kernel and of its point kernel (magi_gradient_bytes): what the PMC
+// passes of profiles/ count at the fabric -- the operator blocks once, the operand planes of one slot parity once per XCD (every XCD's L2
+// fetches the 16-column slices its workgroups share), one 128-entry block vector per (task, product, matrix-core column in use) stored,
+// and the point kernel's re-read of those product slots.
+template <int DRIFT>
+void sep_traffic(const DevProblem& pb, int n, double* stores, double* operands, double* point_reads, double* mirror_writes) {
+    *stores = *operands = *point_reads = *mirror_writes = 0.0;
+    if constexpr (DriftT<DRIFT>::SEP) {
+        using DR = DriftT<DRIFT>;
+        using SL = SepLayout<DRIFT>;
+        double vecs = 0.0;       // block vectors written per chain
+        for (int d = 0; d < DR::D; ++d)
+            for (int kind = 0; kind < 3; ++kind)
+                for (int bi = 0; bi < pb.nb; ++bi)
+                    for (int bj = 0; bj < pb.nb; ++bj) {
+                        if (kind != TK_FE && bj > bi) continue;
+                        if (std::abs(bi - bj) > pb.wb) continue;
+                        const int nbd = DR::nbasis(d);
+                        vecs += kind == TK_FK ? nbd : 1;                                            // row-type product
+                        if (kind == TK_FE || bi != bj) vecs += kind == TK_FH ? 1 : nbd;             // column-type product
+                    }
+        *stores = vecs * n * MAGI_TB * 8.0;
+        const int cw = xop_width(n), groups = (n + 15) >> 4;
+        *operands = 8.0 * groups * DR::D * SL::planes(cw) * (double)pb.Np * 16 * 8.0;
+        int used = 0, basis = 0;
+        for (int sl = 0; sl < SL::PS_TOTAL; ++sl) used += SL::slot_used(sl) ? 1 : 0;
+        for (int d = 0; d < DR::D; ++d) basis += 1 + DR::nbasis(d);
+        const double nslot = (double)std::min(pb.nb, 2 * pb.wb + 1);
+        *point_reads = (double)n * used * nslot * pb.N * 8.0;
+        *mirror_writes = (double)n * basis * pb.N * 8.0;
+    }
+}
+void magi_sep_traffic(const DevProblem& pb, int n_chains, double* stores, double* operands, double* point_reads, double* mirror_writes) {
+#define MAGI_CALL(DR) return sep_traffic<DR>(pb, n_chains, stores, operands, point_reads, mirror_writes)
+    MAGI_DRIFT_DISPATCH(pb.drift, MAGI_CALL);
+#undef MAGI_CALL
 }
 
 int magi_launch_mirror(magi_handle* h, int n_chains, hipStream_t s) {
@@ -1171,3 +1244,27 @@ int magi_launch_leap_finalize(magi_handle* h, int n_chains, double* d_out, hipSt
     if (e != hipSuccess) return magi_fail(h, MAGI_E_HIP, std::string("leap_finalize launch: ") + hipGetErrorString(e));
     return MAGI_OK;
 }
+
+#ifdef MAGI_WG_TRACE
+// dev: `warm` untimed [stream, point] pairs (validation plans, no decisions: as magi_time_gradient), then ONE traced pair; out = [2][4096][4]
+extern "C" int magi_debug_wg_trace(magi_handle* h, int n_chains, int warm, int with_point, unsigned long long* out) {
+    if (!h || !out) return MAGI_E_BADARG;
+    (void)hipSetDevice(h->device);
+    int rc = magi_ensure_chains(h, n_chains);
+    if (rc) return rc;
+    MAGI_HIP_CHECK(h, hipMemsetAsync(h->ch.gctl, 0, sizeof(GlobalCtl), h->stream));
+    if ((rc = magi_launch_prepare(h, n_chains, h->stream))) return rc;
+    if ((rc = magi_launch_plan_eval(h, n_chains, h->stream))) return rc;
+    h->sampler_ready = false;
+    void* sym = nullptr;
+    MAGI_HIP_CHECK(h, hipGetSymbolAddress(&sym, HIP_SYMBOL(g_wg_trace)));
+    for (int i = 0; i <= warm; ++i) {
+        if (i == warm) MAGI_HIP_CHECK(h, hipMemsetAsync(sym, 0, sizeof(unsigned long long) * 2 * 4096 * 4, h->stream));
+        if ((rc = magi_launch_stream(h, n_chains, i & 1, false, h->stream))) return rc;
+        if (with_point && (rc = magi_launch_point(h, n_chains, 0, h->stream))) return rc;
+    }
+    MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    MAGI_HIP_CHECK(h, hipMemcpy(out, sym, sizeof(unsigned long long) * 2 * 4096 * 4, hipMemcpyDeviceToHost));
+    return MAGI_OK;
+}
+#endif

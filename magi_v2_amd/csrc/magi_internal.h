@@ -834,8 +834,25 @@ __device__ inline FinalizeOut finalize_gradient(const DevProblem& pb, double* vb
 // ------------------------------------------------------------------------------------------
 // Host-side handle
 // ------------------------------------------------------------------------------------------
+// Tuning / test switches of a handle.  The environment variables of the same names (MAGI_STREAM_FAMILY, ...) are read ONCE, when the
+// handle is created; afterwards only magi_set_option changes them (no getenv on any compute path: a concurrent setenv cannot race a
+// launch, and a stray variable cannot change what a running job computes between two calls).
+struct MagiOptions {
+    int stream_family = 0;              // 0 auto (leap.hip: magi_stream_family_mc), 1 "mc": every batch on the matrix-core kernel, 2 "valu"
+    int sep_pair_min = 256;             // pack.hip: pair the diagonal blocks FH_bb + FK_bb when there are more tasks than this
+    int fused_parity = 0;               // magi_logpost_grad_fused evaluates as an even (0) / odd (1) leapfrog slot
+    int gemm_remap_min = 24;            // build.hip: super-block tile order from this many super-blocks per launch
+    int potrf_panels = 4;               // build.hip: 128-wide panels per block column of the Cholesky factorisation
+    long long slot_budget_graphs = 0;   // TEST HOOK: cap on the graph launches of one magi_sampler_run (0 = the computed bound)
+    int no_graph = 0;                   // launch the leapfrog slots directly (debugging, long rocprofv3 kernel traces)
+    int fit_host_loop = 0, fit_per_component = 0;      // build.hip: A/B paths of the hyper-parameter fit
+    int build_profile = 0, build_serial = 0;           // build.hip: per-class device times (serialises), one component per group
+};
+void magi_options_from_env(MagiOptions& o);               // capi.hip
+
 struct magi_handle {
     int device = 0;
+    MagiOptions opt;
     hipStream_t stream = nullptr;
     std::string err;
 
@@ -911,7 +928,7 @@ int magi_launch_stream(magi_handle* h, int n_chains, int parity, bool with_decis
 int magi_launch_point(magi_handle* h, int n_chains, int parity, hipStream_t s);                            // k_point: leapfrog epilogue per grid point
 int magi_launch_leap_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s, int parity = 0);
 int magi_leap_wgs(const DevProblem& pb);
-bool magi_stream_family_mc(int n_chains, int n_tasks);        // leap.hip
+bool magi_stream_family_mc(const magi_handle* h, int n_chains);        // leap.hip
 int magi_build_profile_get(double* flops, double* ms, long* calls);           // build.hip
 int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const double* X, const double* mu, const double* mu_phi2,
                             const double* sd_phi2, const double* sig_loc, double nu, int iters, double lr, double jitter,
@@ -925,6 +942,7 @@ int magi_launch_mirror(magi_handle* h, int n_chains, hipStream_t s);    // leap.
 bool magi_drift_separable(int drift);                                   // leap.hip
 size_t magi_sep_tpart_elems(const DevProblem& pb, int n_chains);        // leap.hip: doubles in tpart / vop for the separable path
 size_t magi_sep_vop_elems(const DevProblem& pb, int n_chains);
+void magi_sep_traffic(const DevProblem& pb, int n_chains, double* stores, double* operands, double* point_reads, double* mirror_writes);   // leap.hip
 int magi_launch_init_chains(magi_handle* h, const long long* d_chain_ids, hipStream_t s);
 int magi_ensure_chains(magi_handle* h, int n_chains);
 // build.hip: dense device matrices -> packed device storage (sym / transpose / band)

@@ -185,9 +185,8 @@ int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double*
         const int n_tasks = (int)(tasks.size() / 4);
         // tasks of the separable streaming kernel: as above, with FH_bb + FK_bb of a component paired (equal work per workgroup) -- when there
         // are more tasks than CUs.  On a small grid every task has a CU of its own and the kernel lasts as long as its longest workgroup: a
-        // pair's 16 dependent steps would be that workgroup (N = 161, b = 80, 8 chains: MAGI_SEP_PAIR_MIN=0 forces the pairs for A/B).
-        const char* pair_env = getenv("MAGI_SEP_PAIR_MIN");
-        const bool pair_diag = n_tasks > (pair_env ? atoi(pair_env) : 256);
+        // pair's 16 dependent steps would be that workgroup (N = 161, b = 80, 8 chains: option sep_pair_min = 0 forces the pairs for A/B).
+        const bool pair_diag = n_tasks > h->opt.sep_pair_min;
         std::vector<int> stasks;
         for (int i = 0; i < n_tasks; ++i) {
             const int d = tasks[4 * i], kind = tasks[4 * i + 1], bi = tasks[4 * i + 2], bj = tasks[4 * i + 3];

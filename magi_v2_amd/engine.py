@@ -69,6 +69,8 @@ _SYMBOLS = {
     "magi_sampler_profile": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _lp]),
     "magi_time_gradient": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp]),
     "magi_gradient_bytes": (C.c_int, [C.c_void_p, C.c_int, _dp]),
+    "magi_stream_kernel_name": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
+    "magi_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "magi_debug_par": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "magi_build_profile": (C.c_int, [C.c_void_p, _dp, _dp, _lp]),
 }
@@ -162,6 +164,19 @@ class MagiEngine:
     @staticmethod
     def version():
         return load_library().magi_version().decode()
+
+    _FAMILIES = {"auto": 0, "mc": 1, "valu": 2}
+
+    def set_option(self, name, value):
+        """Tuning / test switch of this handle (include/magi_hip.h: magi_set_option); stream_family also takes "auto" / "mc" / "valu"."""
+        if name == "stream_family" and isinstance(value, str):
+            value = self._FAMILIES[value]
+        self._check(self._lib.magi_set_option(self._h, name.encode(), int(value)))
+
+    def stream_kernel_name(self, n_chains=1):
+        buf = C.create_string_buffer(64)
+        self._check(self._lib.magi_stream_kernel_name(self._h, int(n_chains), buf, 64))
+        return buf.value.decode()
 
     # -- matrices -------------------------------------------------------------------------------
     def build_matrices(self, I, phi1s, phi2s, nu=2.01, bandsize=None, want_host=True):
@@ -379,7 +394,7 @@ class MagiEngine:
                      "single_phase_operators")
 
     def build_profile(self):
-        """Per-class (flops, ms, calls) of the last build_matrices run under MAGI_BUILD_PROFILE=1."""
+        """Per-class (flops, ms, calls) of the last build_matrices run with set_option("build_profile", 1)."""
         f, ms = np.zeros(16), np.zeros(16)
         calls = np.zeros(16, dtype=np.int64)
         n = self._lib.magi_build_profile(self._h, _ptr(f), _ptr(ms), calls.ctypes.data_as(_lp))

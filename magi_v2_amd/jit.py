@@ -7,6 +7,7 @@ files that do not depend on the drift reuse the base build's objects.  Results a
 import fcntl
 import glob
 import hashlib
+import logging
 import os
 import shutil
 import subprocess
@@ -34,29 +35,43 @@ def _source_digest() -> str:
 
 
 def _compiler_version() -> str:
-    """``hipcc --version`` ("" when there is no compiler on this machine)."""
+    """``hipcc --version`` ("" when the compiler cannot be run)."""
     try:
         return subprocess.run([_hipcc(), "--version"], capture_output=True, check=False).stdout.decode(errors="replace")
     except OSError:
         return ""
 
 
-def _cached_library_usable(d: str, lib: str) -> bool:
-    """A library built from these very sources for this very drift header exists: use it when it was built by the compiler found
-    here, when there is NO compiler here (a deployment box that received a prebuilt ``jit_cache/``), or when the caller vouches for
-    it with MAGI_JIT_CACHE_TRUST=1; otherwise it is rebuilt (same sources, another compiler)."""
-    if not os.path.exists(lib):
-        return False
-    if os.environ.get("MAGI_JIT_CACHE_TRUST") == "1":
-        return True
+def _no_compiler_here() -> bool:
+    """A deployment box that received a prebuilt ``jit_cache/``: HIPCC is not set and there is no hipcc at the default place or on PATH.
+    (A HIPCC that is set but cannot be run is a configuration error, not "no compiler": nothing is trusted on its account.)"""
+    return "HIPCC" not in os.environ and not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None
+
+
+def _lib_name(compiler_version: str) -> str:
+    """The library's file name carries a digest of the compiler that built it: libraries of two compilers live side by side in one
+    cache directory (the directory key is compiler-free), nothing beside the library has to agree with it, and ``os.replace`` of the
+    finished file is the one atomic publication."""
+    return "libmagi_hip_user.%s.so" % hashlib.sha256(compiler_version.encode()).hexdigest()[:10]
+
+
+def _find_cached_library(d: str):
+    """The usable library in cache directory ``d`` (built from these very sources for this very drift header), or None:
+    the one built by the compiler found here; with NO compiler here, or when the caller vouches for the cache with
+    MAGI_JIT_CACHE_TRUST=1, the most recent one of any compiler (logged: its compiler is not verified)."""
     here = _compiler_version()
-    if not here:
-        return True
-    try:
-        with open(os.path.join(d, "compiler.txt")) as fh:
-            return fh.read() == here
-    except OSError:
-        return False
+    if here:
+        lib = os.path.join(d, _lib_name(here))
+        if os.path.exists(lib):
+            return lib
+    trust = os.environ.get("MAGI_JIT_CACHE_TRUST") == "1"
+    if trust or (not here and _no_compiler_here()):
+        libs = sorted(glob.glob(os.path.join(d, "libmagi_hip_user.*.so")), key=os.path.getmtime, reverse=True)
+        if libs:
+            logging.getLogger(__name__).warning("using %s without verifying its compiler (%s)", libs[0],
+                                                "MAGI_JIT_CACHE_TRUST=1" if trust else "no hipcc on this machine")
+            return libs[0]
+    return None
 
 
 def prune(keep_latest: int = 1) -> None:
@@ -79,16 +94,20 @@ def library_for(drift, verbose: bool = False) -> str:
     finished library is moved into place with one ``os.replace``."""
     if drift.header is None:
         raise ValueError("built-in drifts use the base library")
-    key = hashlib.sha256((drift.header + _source_digest()).encode()).hexdigest()[:16]       # (the compiler is NOT in the key: see _cached_library_usable)
+    key = hashlib.sha256((drift.header + _source_digest()).encode()).hexdigest()[:16]       # (the compiler is NOT in the key: it is in the library's file name)
     d = os.path.join(CACHE, f"{drift.name}_{key}")
-    lib = os.path.join(d, "libmagi_hip_user.so")
-    if _cached_library_usable(d, lib):
-        return lib
+    found = _find_cached_library(d)
+    if found:
+        return found
+    version = _compiler_version()
+    if not version:
+        raise RuntimeError(f"no library for drift '{drift.name}' in {d} and {_hipcc()} cannot be run to build one")
+    lib = os.path.join(d, _lib_name(version))
     os.makedirs(d, exist_ok=True)
     with open(os.path.join(d, ".lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if _cached_library_usable(d, lib):            # another process built it while we waited
+            if os.path.exists(lib):                       # another process built it while we waited
                 return lib
             hdr = os.path.join(d, "user_drift.h")
             tmp_hdr = hdr + f".{os.getpid()}.tmp"
@@ -121,10 +140,7 @@ def library_for(drift, verbose: bool = False) -> str:
                         raise RuntimeError("hipcc failed for the traced drift:\n" + out.decode(errors="replace")[-4000:])
                 tmp = os.path.join(work, "libmagi_hip_user.so")
                 subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-Wl,-rpath,/opt/rocm/lib"])
-                with open(os.path.join(d, f"compiler.txt.{os.getpid()}.tmp"), "w") as fh:
-                    fh.write(_compiler_version())
-                os.replace(os.path.join(d, f"compiler.txt.{os.getpid()}.tmp"), os.path.join(d, "compiler.txt"))
-                os.replace(tmp, lib)
+                os.replace(tmp, lib)                      # (the one publication: the name says which compiler built it)
             finally:
                 shutil.rmtree(work, ignore_errors=True)
             return lib

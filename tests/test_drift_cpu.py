@@ -141,21 +141,30 @@ def test_jit_library_for_is_safe_under_concurrent_callers(tmp_path, monkeypatch)
 
 
 def test_prebuilt_jit_cache_is_used_without_a_compiler_and_rebuilt_for_another_one(monkeypatch):
-    """The cache key of a drift-specialised library is (drift header, library sources, extra flags) -- NOT the compiler: a box
-    that receives a prebuilt jit_cache/ and has no hipcc uses it as is, MAGI_JIT_CACHE_TRUST=1 vouches for it across compiler
-    versions, and only a box with a DIFFERENT compiler rebuilds (compiler.txt beside the library records who built it)."""
+    """The cache key of a drift-specialised library is (drift header, library sources, extra flags) -- NOT the compiler, whose digest is
+    in the library's FILE NAME: a box that receives a prebuilt jit_cache/ and has no hipcc uses what is there, MAGI_JIT_CACHE_TRUST=1
+    vouches for it across compiler versions, a box with a DIFFERENT compiler builds its own file beside it (no rebuilding over each
+    other), and a HIPCC that is set but cannot be run is an error, not "no compiler"."""
     from magi_v2_amd import drift, jit
     from magi_v2_amd.drift_examples import EXAMPLES
     f, D, P = EXAMPLES["lotka_volterra"]
     d = drift.resolve(f, D, P)
     lib = jit.library_for(d)                                # built (or found) by this container's compiler
     folder = os.path.dirname(lib)
-    assert open(os.path.join(folder, "compiler.txt")).read() == jit._compiler_version() != ""
+    assert jit._compiler_version() != "" and os.path.basename(lib) == jit._lib_name(jit._compiler_version())
     stamp = os.path.getmtime(lib)
-    monkeypatch.setenv("HIPCC", "/nonexistent/hipcc")       # no compiler on this "box": the prebuilt library is used
-    assert jit._compiler_version() == "" and jit.library_for(d) == lib and os.path.getmtime(lib) == stamp
-    monkeypatch.delenv("HIPCC")
+    assert jit.library_for(d) == lib and os.path.getmtime(lib) == stamp          # found again, not rebuilt
+    # a box without any compiler: the prebuilt library is used as is
+    monkeypatch.setattr(jit, "_compiler_version", lambda: "")
+    monkeypatch.setattr(jit, "_no_compiler_here", lambda: True)
+    assert jit.library_for(d) == lib and os.path.getmtime(lib) == stamp
+    # HIPCC set but not runnable: a configuration error -- the cache is not trusted on its account
+    monkeypatch.setattr(jit, "_no_compiler_here", lambda: False)
+    assert jit._find_cached_library(folder) is None
+    with pytest.raises(RuntimeError):
+        jit.library_for(d)
+    # another compiler: its own file name, so this one is not "usable" for it ...
     monkeypatch.setattr(jit, "_compiler_version", lambda: "some other hipcc 9.9")
-    assert not jit._cached_library_usable(folder, lib)      # another compiler: rebuild ...
+    assert jit._lib_name("some other hipcc 9.9") != os.path.basename(lib) and jit._find_cached_library(folder) is None
     monkeypatch.setenv("MAGI_JIT_CACHE_TRUST", "1")
-    assert jit._cached_library_usable(folder, lib)          # ... unless the caller vouches for the cache
+    assert jit._find_cached_library(folder) == lib          # ... unless the caller vouches for the cache

@@ -69,6 +69,52 @@ def test_full_size_logpost_consistency_and_gradient(N, band):
     eng.close()
 
 
+def test_logpost_at_n4096_against_the_cpu_oracle():
+    """The first CPU truth for the dense paths above 8 block rows: at N = 4096 x 4 (8 448 operator blocks, 1.1 GB) the three stacks the
+    GPU built are downloaded once (magi_get_dense, 1.6 GB) and the oracle -- the numpy restatement of magi_v2.py:308-348, pinned to the
+    golden vectors at small N -- evaluates log posterior and gradient on them: the reference-order three-phase kernels to 1e-10, the
+    sampler's single-phase kernels to 1e-9, for one state (VALU streaming kernel) and for a batch of three (matrix-core kernel).
+    (At N = 8192 the same comparison would move 6.4 GB and minutes of numpy: the kernels are the same code with more blocks.)"""
+    from magi_v2_amd.engine import MagiEngine
+    from oracle import magi_oracle as orc
+    N = 4096
+    I, X_obs, truth, th = host.synthetic_seir(N, seed=0)
+    Xi = host.linear_interpolate(X_obs)
+    hp = host.hparams_initial(Xi)
+    N_ds, beta, idx, y = host.observation_bookkeeping(X_obs, X_obs)
+    Xhat = host.cubic_smoother(I, Xi)
+    LB = host.sigma_sqs_lower_bound(Xhat)
+    eng = MagiEngine(0)
+    eng.build_matrices(I, hp["phi1s"], hp["phi2s"], 2.01, want_host=False)
+    eng.set_problem(Xi.mean(axis=0), N_ds.astype(np.float64), idx, y, beta, LB, "seir4")
+    C_inv, m, K_inv = eng.get_dense()
+    pr = orc.Problem(I=I, mu=Xi.mean(axis=0), C_inv=C_inv, m=m, K_inv=K_inv, N_ds=N_ds.astype(np.float64), obs_idx=idx, y=y, beta=float(beta),
+                     LB=LB, drift="seir4", P=3)
+    sp, tp = host.softplus_inverse_inits(hp["sigma_sqs"], th, LB)
+    rng = np.random.default_rng(4096)
+    Xb = Xhat[None] + 0.01 * rng.standard_normal((3,) + Xhat.shape)
+    spb = sp[None] + 0.1 * rng.standard_normal((3, 4))
+    tpb = tp[None] + 0.1 * rng.standard_normal((3, 3))
+    truth_b = [orc.logpost_grad(Xb[c], spb[c], tpb[c], 0.8, pr) for c in range(3)]
+    assert eng.stream_kernel_name(1) == "k_stream<1>" and eng.stream_kernel_name(3).startswith("k_stream_sep")
+
+    def check(got, ref, tol):
+        l0, gx0, gs0, gt0 = ref
+        assert abs(got[0] - l0) <= tol * abs(l0), (got[0], l0)
+        assert np.abs(got[1] - gx0).max() <= tol * np.abs(gx0).max()
+        assert np.abs(got[2] - gs0).max() <= tol * np.abs(gs0).max()
+        assert np.abs(got[3] - gt0).max() <= tol * np.abs(gt0).max()
+
+    check(eng.logpost_grad(Xb[0], spb[0], tpb[0], 0.8), truth_b[0], 1e-10)                # three phases, reference op order
+    check(eng.logpost_grad(Xb[0], spb[0], tpb[0], 0.8, fused=True), truth_b[0], 1e-9)     # k_stream<1> + k_point
+    three = eng.logpost_grad(Xb, spb, tpb, 0.8)
+    fused = eng.logpost_grad(Xb, spb, tpb, 0.8, fused=True)                                # k_stream_sep + k_point (separable path)
+    for c in range(3):
+        check([a[c] for a in three], truth_b[c], 1e-10)
+        check([a[c] for a in fused], truth_b[c], 1e-9)
+    eng.close()
+
+
 def test_config5_sampler_runs_at_n8192():
     """BASELINE config 5 (N = 8192 x 4, one chain): the block-streaming sampler on 33 024 operator blocks (4.4 GB) -- a few
     NUTS transitions stay finite, move the state and take leapfrogs; the fixed-L mode does the same work per leapfrog."""
@@ -114,8 +160,11 @@ def test_full_size_inverse_properties(N, remap, panels):
     EPS = np.finfo(float).eps
     I = np.arange(N) * 0.025
     eng = MagiEngine(0)
-    with _env(MAGI_GEMM_REMAP_MIN=remap, MAGI_POTRF_PANELS=panels):
-        C_inv, m, K_inv = eng.build_matrices(I, [0.05], [0.1], 2.01)
+    if remap is not None:
+        eng.set_option("gemm_remap_min", remap)
+    if panels is not None:
+        eng.set_option("potrf_panels", panels)
+    C_inv, m, K_inv = eng.build_matrices(I, [0.05], [0.1], 2.01)
     Kap, pK, Kpp = eng.matern_blocks(I, 0.05, 0.1, 2.01)
     cols = np.random.default_rng(0).integers(0, N, 16)
     cond = np.linalg.cond(Kap)
@@ -154,9 +203,10 @@ def test_remapped_tile_order_is_bit_identical_n2048():
 
     def build(remap):
         eng = MagiEngine(0)
-        with _env(MAGI_GEMM_REMAP_MIN=remap):
-            mats = eng.build_matrices(I, hp["phi1s"], hp["phi2s"], 2.01)
-            eng.set_problem(Xi.mean(axis=0), N_ds.astype(np.float64), idx, y, beta, LB, "seir4")
+        if remap is not None:
+            eng.set_option("gemm_remap_min", remap)
+        mats = eng.build_matrices(I, hp["phi1s"], hp["phi2s"], 2.01)
+        eng.set_problem(Xi.mean(axis=0), N_ds.astype(np.float64), idx, y, beta, LB, "seir4")
         out = mats + tuple(eng.logpost_grad(X, sp, tp, 0.8, fused=True))
         eng.close()
         return out

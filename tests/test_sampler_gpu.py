@@ -245,13 +245,13 @@ def test_slot_budget_exit_reports_the_stuck_chain_and_the_handle_stays_usable(mo
     X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], np.ones(pr.P), pr.LB)
     cfg = eng.default_cfg(num_results=2, num_burnin_steps=6, step_size=1e-3)        # (a small first step: deep trees, > 64 slots)
     eng.sampler_init(cfg, X0, s0, t0, seed=1234)
-    monkeypatch.setenv("MAGI_SLOT_BUDGET_GRAPHS", "1")
+    eng.set_option("slot_budget_graphs", 1)
     with pytest.raises(MagiHipError) as ei:
         eng.sampler_run(8)
     assert ei.value.code == -5 and "slot budget" in str(ei.value) and "chain 0: k=" in str(ei.value)
     with pytest.raises(MagiHipError):                  # the interrupted sampler refuses to go on
         eng.sampler_run(1)
-    monkeypatch.delenv("MAGI_SLOT_BUDGET_GRAPHS")
+    eng.set_option("slot_budget_graphs", 0)
     eng.sampler_init(cfg, X0, s0, t0, seed=1234)
     lf, _ = eng.sampler_run(8)
     slots, graphs = eng.sampler_run_stats()
@@ -293,6 +293,37 @@ def test_checkpoint_resume_in_a_new_handle_continues_the_run_bit_for_bit(n_chain
         np.testing.assert_array_equal(a, b)
     for f in ("leapfrogs_taken", "tree_depth", "step_size", "target_log_prob", "is_accepted"):
         np.testing.assert_array_equal(getattr(dfull, f)[:, 7:], getattr(dpart, f)[:, 7:])
+
+
+def test_checkpoint_of_another_run_or_with_broken_scalars_is_rejected():
+    """A resume promises the uninterrupted run bit for bit, which holds only under the same cfg / seed / chain ids: the scalars carry a tag of
+    those and magi_sampler_set_checkpoint refuses anything else (MAGI_E_BADARG), as it refuses NaN / fractional / out-of-range scalars
+    instead of casting them."""
+    from magi_v2_amd.engine import MagiHipError
+    g = load_g4("seir4_N81")
+    pr = problem_from_g4(g, None)
+    X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], np.ones(pr.P), pr.LB)
+    eng = engine_for(pr, None)
+    cfg = eng.default_cfg(num_results=3, num_burnin_steps=5)
+    eng.sampler_init(cfg, X0, s0, t0, seed=17, chain_ids=[4])
+    eng.sampler_run(3)
+    ck = eng.sampler_checkpoint()
+    for kw in (dict(seed=18, chain_ids=[4]), dict(seed=17, chain_ids=[5])):                    # another seed / another Philox stream
+        with pytest.raises(MagiHipError) as ei:
+            eng.sampler_resume(cfg, ck, **kw)
+        assert ei.value.code == -1 and "another sampler configuration" in str(ei.value)
+    with pytest.raises(MagiHipError):                                                          # another burn-in
+        eng.sampler_resume(eng.default_cfg(num_results=3, num_burnin_steps=6), ck, seed=17, chain_ids=[4])
+    for col, bad in ((0, np.nan), (0, 2.5), (0, 99.0), (1, -1.0), (2, 0.0), (2, np.inf), (3, np.nan), (6, 0.0), (6, 1.5), (7, np.nan), (7, 2.5)):
+        broken = dict(ck, scalars=ck["scalars"].copy())
+        broken["scalars"][0, col] = bad
+        with pytest.raises(MagiHipError) as ei:
+            eng.sampler_resume(cfg, broken, seed=17, chain_ids=[4])
+        assert ei.value.code == -1, (col, bad)
+    eng.sampler_resume(cfg, ck, seed=17, chain_ids=[4])                                       # the untouched checkpoint still resumes
+    eng.sampler_run(5)
+    assert list(eng.sampler_steps_done()) == [8]
+    eng.close()
 
 
 @pytest.mark.parametrize("tag,chains,band", [("sirw_N41", 1, None), ("sirw_N41", 2, None), ("sirw_N41", 3, None), ("seir3_N161", 1, None), ("seir3_N161", 2, None),
@@ -342,10 +373,11 @@ def test_fused_log_posterior_is_the_same_in_even_and_odd_slots(tag, monkeypatch,
     for n in (1, 2, 5):
         X = X0[None] + 0.01 * np.random.default_rng(n).standard_normal((n,) + X0.shape)
         sp, tp = np.repeat(s0[None], n, 0), np.repeat(t0[None], n, 0)
-        monkeypatch.setenv("MAGI_FUSED_PARITY", "0")
+        eng.set_option("fused_parity", 0)
         even = eng.logpost_grad(X, sp, tp, 1.0, fused=True)
-        monkeypatch.setenv("MAGI_FUSED_PARITY", "1")
+        eng.set_option("fused_parity", 1)
         odd = eng.logpost_grad(X, sp, tp, 1.0, fused=True)
+        eng.set_option("fused_parity", 0)
         ref = eng.logpost_grad(X, sp, tp, 1.0)
         for a, b in zip(even, odd):
             np.testing.assert_array_equal(a, b)
