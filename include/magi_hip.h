@@ -218,6 +218,16 @@ int magi_sample(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains,
                 uint64_t seed, const int64_t* chain_ids,
                 double* X_samps, double* sig_pre_samps, double* th_pre_samps);
 
+/* theta initialiser of initial_fit (magi_v2.py:133-179): Adam(learning_rate) x num_iters, from theta[P] as passed
+ * in (the reference starts at 1), on theta_objective = sum_d toNorm_d^T K_d^-1 toNorm_d with toNorm = reshape(f(Xhat, theta),
+ * [D, N, 1]) - m_d (Xhat - mu)_d -- including the reference's reshape (:155-156) -- evaluated with the device-resident UNbanded
+ * m and K^-1 stacks (the initialiser runs before the band approximation).  The whole loop stays on the device: one captured graph
+ * per Adam step (drift values + theta-Jacobian, K^-1 r, K^-T r, reduction + update), the host waits once.  Xhat[N][D] row-major,
+ * mu[D]; theta[P] in/out; loss_trace[num_iters] (optional) receives the objective at every step.  tf_keras Adam restated from its
+ * documented defaults: parity unpinned. */
+int magi_theta_init(magi_handle* h, int drift_id, int P, const double* Xhat, const double* mu, int num_iters, double learning_rate,
+                    double* theta, double* loss_trace);
+
 /* ---- instrumentation (bench.py roofline leg) ----------------------------------------------- */
 
 /* Launch one gradient evaluation (the 3 mat-vec phases + reduce) `reps` times on the handle's

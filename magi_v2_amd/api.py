@@ -270,6 +270,10 @@ class MAGI_v2:
             A = np.einsum("dip,diq->pq", F, KF)
             g0 = np.einsum("dip,di->p", KF + KTF, bvec)                          # gradient offset
             grad_fn = lambda th: (A + A.T) @ th - g0
+        elif self._dev_valid and not self._host_overrides():
+            # the general branch stays on the GPU: drift values, theta-Jacobian, (K^-1 + K^-T) r and the Adam update of every step in one
+            # captured graph, the host waits once (csrc/thetainit.hip); 10 000 steps at N = 161: a fraction of a second
+            return self.engine.theta_init(self.drift, self.Xhat_init, self.mu_ds, iters)
         else:
             def grad_fn(th):
                 fv = f_np(self.I, self.Xhat_init, th).reshape(D, n)              # the reshape quirk

@@ -339,6 +339,23 @@ int magi_dense_apply(magi_handle* h, int which, int transpose, int nv, const dou
     return MAGI_OK;
 }
 
+int magi_theta_init(magi_handle* h, int drift_id, int P, const double* Xhat, const double* mu, int num_iters, double learning_rate,
+                    double* theta, double* loss_trace) {
+    if (!h) return MAGI_E_BADARG;
+    if (!Xhat || !mu || !theta) return magi_fail(h, MAGI_E_BADARG, "null pointer");
+    if (!h->dDense[0] || h->dense_N <= 0) return magi_fail(h, MAGI_E_STATE, "no resident matrices: build or set them first");
+    if (num_iters < 0 || !(learning_rate > 0.0)) return magi_fail(h, MAGI_E_BADARG, "num_iters >= 0 and learning_rate > 0");
+#ifdef MAGI_USER_DRIFT_HEADER
+    if (drift_id != MAGI_DRIFT_USER) return magi_fail(h, MAGI_E_BADARG, "this library is specialised for a traced f_vec: drift id must be MAGI_DRIFT_USER");
+#else
+    if (drift_id < MAGI_DRIFT_SEIR3 || drift_id > MAGI_DRIFT_SIRW) return magi_fail(h, MAGI_E_BADARG, "unknown drift id (a traced f_vec needs its own library: magi_v2_amd.jit)");
+#endif
+    for (int i = 0; i < h->dense_N * h->dense_D; ++i)
+        if (std::isnan(Xhat[i])) return magi_fail(h, MAGI_E_NAN, "NaN in Xhat");
+    (void)hipSetDevice(h->device);
+    return magi_theta_init_device(h, drift_id, P, Xhat, mu, num_iters, learning_rate, theta, loss_trace);
+}
+
 int magi_build_matrices(magi_handle* h, const double* I, int N, int D, const double* phi1, const double* phi2,
                         double nu, int bandsize, double* C_inv, double* m, double* K_inv) {
     if (!h) return MAGI_E_BADARG;

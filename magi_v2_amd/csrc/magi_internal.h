@@ -871,7 +871,7 @@ struct magi_handle {
     size_t tiles_cap = 0, tasks_cap = 0;
     // work space of the matrix build and the packing, kept between calls (grow-only): a repeated build at N = 8192 otherwise spends
     // more host time in hipMalloc / hipFree of ~35 GB than the GPU spends on the build
-    enum { WS_KAP = 0, WS_P, WS_PP, WS_DINV, WS_PANEL, WS_TCS, WS_TM, WS_TKS, WS_TE, WS_APPLY, WS_COUNT };
+    enum { WS_KAP = 0, WS_P, WS_PP, WS_DINV, WS_PANEL, WS_TCS, WS_TM, WS_TKS, WS_TE, WS_APPLY, WS_TI, WS_COUNT };
     double* ws[WS_COUNT] = {};
     size_t ws_cap[WS_COUNT] = {};
 
@@ -957,5 +957,7 @@ int magi_build_dense_device(magi_handle* h, const double* I, int N, int D, int n
 int magi_ensure_dense(magi_handle* h, int N, int D);
 // pack.hip: Y[d] = A_d V[d] or A_d^T V[d] for the resident dense stack `which` (0 C^-1, 1 m, 2 K^-1); V, Y device [D][N][nv]
 int magi_dense_apply_device(magi_handle* h, int which, int trans, int nv, const double* dV, double* dY);
+// thetainit.hip: Adam x iters on the theta objective of magi_v2.py:148-158 with the resident UNbanded stacks, one captured graph per step
+int magi_theta_init_device(magi_handle* h, int drift, int P, const double* Xhat, const double* mu, int iters, double lr, double* theta, double* loss_trace);
 int magi_matern_blocks_device(magi_handle* h, const double* I, int N, double phi1, double phi2, double nu,
                               double* Kappa, double* p_Kappa, double* Kappa_pp);

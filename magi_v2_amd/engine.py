@@ -48,6 +48,7 @@ _SYMBOLS = {
     "magi_fit_hparams": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_double,
                                    C.c_double, _dp, _dp, _dp, _dp]),
     "magi_set_matrices": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]),
+    "magi_theta_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_double, _dp, _dp]),
     "magi_build_dense": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, C.c_int, _ip, _dp, _dp, C.c_double]),
     "magi_pack_resident": (C.c_int, [C.c_void_p, C.c_int]),
     "magi_get_dense": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
@@ -236,6 +237,20 @@ class MagiEngine:
         if want_trace:
             out["loss"] = trace[:num_iters]
         return out
+
+    def theta_init(self, drift, Xhat, mu, num_iters=10000, learning_rate=0.01, theta0=None, want_trace=False):
+        """magi_v2.py:133-179 on the GPU (magi_theta_init): the whole Adam loop on the device-resident UNbanded matrices, any drift
+        this library carries (``drift``: built-in name or the traced Drift the engine was created for).  Returns theta[P] (, losses)."""
+        if isinstance(drift, str):
+            P, drift_id = DRIFT_SHAPES[drift][1], DRIFT_IDS[drift]
+        else:
+            P, drift_id = drift.P, drift.device_id
+        Xhat = _f64(Xhat, (self.N, self.D))
+        th = np.ones(P) if theta0 is None else _f64(theta0, (P,)).copy()
+        trace = np.zeros(max(num_iters, 1)) if want_trace else None
+        self._check(self._lib.magi_theta_init(self._h, drift_id, P, _ptr(Xhat), _ptr(_f64(mu, (self.D,))), int(num_iters), float(learning_rate),
+                                              _ptr(th), _ptr(trace)))
+        return (th, trace[:num_iters]) if want_trace else th
 
     def matern_blocks(self, I, phi1, phi2, nu=2.01):
         I = _f64(np.asarray(I).reshape(-1))

@@ -71,3 +71,13 @@ def test_stream_kernels_spill_no_vector_register(tmp_path):
         assert spills == 0, (name, spills)
         assert occ >= 3, (name, occ)
     assert seen >= 6
+
+
+def test_host_side_of_the_c_abi_is_clean_under_asan_and_ubsan():
+    """SURVEY section 5 (sanitizers): csrc/capi.hip compiled with -fsanitize=address,undefined for the HOST (GPU AddressSanitizer is not
+    available on this pool) and driven through everything reachable without a GPU -- creation with no device, every entry point on a
+    NULL handle, the out-parameter helpers (tools/sanitize_host.py; with --gpu on a GPU box it goes on through a live handle)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sanitize_host.py")], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "sanitizer run clean" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

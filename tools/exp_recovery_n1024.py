@@ -44,7 +44,7 @@ def run(label, fit_kw, stale, seed=123):
            "theta_mean_per_chain": th.mean(axis=1).tolist(),
            "sigma_mean": np.sqrt(res["sigma_sqs_samps"].reshape(-1, 4).mean(axis=0)).tolist(), "true_noise_sd": true_sd.tolist(),
            "trajectory_rmse_vs_truth": np.sqrt(((Xm - truth) ** 2).mean(axis=0)).tolist(),
-           "is_accepted": float(np.asarray(kr["is_accepted"]).mean()), "is_accepted_post_burnin": float(np.asarray(kr["is_accepted"]).reshape(NCH, -1)[:, B:].mean()),
+           "is_accepted": float(np.asarray(kr["is_accepted"]).mean()),
            "mean_depth": float(np.asarray(kr["tree_depth"]).mean()), "mean_leapfrogs": float(np.asarray(kr["leapfrogs_taken"]).mean()),
            "step_size_last": float(np.asarray(kr["step_size"]).reshape(NCH, -1)[0, -1]),
            "target_first": float(np.asarray(kr["target_log_prob"]).reshape(NCH, -1)[0, 0]), "target_last": float(np.asarray(kr["target_log_prob"]).reshape(NCH, -1)[0, -1]),
