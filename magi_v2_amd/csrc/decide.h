@@ -97,9 +97,15 @@ __device__ __forceinline__ LeafPlan make_leaf_plan(const ChainCtl& c, unsigned l
 
 // All threads of a 256-thread workgroup call it; `parity` = slot whose stream is running next to these decisions
 // (they complete slot parity ^ 1 ... i.e. the slot the point phase executed last, and write plan[parity]).
-// (Round 3 found this path at the edge of what the register allocator handles: with a pass for another kernel family merely COMPILED into the
-// one-chain SIRW instantiation -- never executed -- it sampled wrong energies (tools/exp_family_hmc.py).  Every instantiation is therefore held
-// to an oracle run with deep trees, tests/test_sampler_gpu.py; the state-sized passes have since moved to the point kernel, boundary_block.)
+// (Round 3: with a pass for another kernel family merely COMPILED into the one-chain SIRW instantiation -- never executed -- it sampled wrong
+// energies (tools/exp_family_hmc.py).  Diagnosed in round 4: a hipcc (ROCm 7.2) defect, not undefined behaviour of this source.  Behind
+// `if (tid == 0) shs[4] = temperature(..)` the register allocator's live-range split copies of three wave-uniform values kept in vector
+// registers -- the chain's cached temperature among them -- were placed IN FRONT of the join block's `s_or_b64 exec, exec, sN`, i.e. they ran
+// for lane 0 only; lanes 1..255 then computed the doubling's first half step with hs = 0.5 eps beta = 0.  The copies appear only where
+// calls to the noinline transcendentals, inter-procedural register allocation and SGPR spills into VGPR lanes meet (each of
+// -mllvm -enable-ipra=false, -mllvm -amdgpu-spill-sgpr-to-vgpr=false, inlined m_exp / m_log removes them).  Guard: magi_v2_amd/isa_check.py
+// scans the ISA of every translation unit at build time for vector instructions in front of a join block's EXEC restore; a flagged unit is
+// rebuilt without IPRA, and the build fails if the shape persists.  Every instantiation is still held to an oracle run with deep trees.)
 template <int DRIFT>
 __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChains& ch, const SamplerCfgDev& cfg, int chain, int parity, int all_done,
                                              double* sh /* 25*16 */, double* shs /* 24 */, ChainCtl* s_ctl, int* s_g, double* s_par /* PAR_COUNT */, double* s_ops /* OPS_COUNT * OPS_W */, double* s_cst /* 3 * MAGI_MAX_D: N_ds, LB, mu */) {

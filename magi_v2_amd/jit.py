@@ -118,7 +118,7 @@ def library_for(drift, verbose: bool = False) -> str:
             try:
                 hipcc = _hipcc()
                 wide = drift.D > 4 or drift.P > 6         # wider per-point lane groups / parameter blocks than the base build's
-                objs, procs = [], []
+                objs, jobs = [], []
                 for src in _build.sources():
                     base = os.path.basename(src)
                     shared = os.path.join(_build.HERE, "build", base + ".o")
@@ -130,14 +130,12 @@ def library_for(drift, verbose: bool = False) -> str:
                     contract = [] if base == "build.hip" else ["-ffp-contract=on"]
                     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-function",
                            f'-DMAGI_USER_DRIFT_HEADER="{hdr}"'] + ((["-DMAGI_MAX_D=8"] if drift.D > 4 else []) + (["-DMAGI_MAX_P=8"] if drift.P > 6 else [])) + \
-                        contract + os.environ.get("MAGI_EXTRA_CFLAGS", "").split() + ["-c", src, "-o", obj]
-                    if verbose:
-                        print(" ".join(cmd), flush=True)
-                    procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-                for cmd, p in procs:
-                    out, _ = p.communicate()
-                    if p.returncode != 0:
-                        raise RuntimeError("hipcc failed for the traced drift:\n" + out.decode(errors="replace")[-4000:])
+                        contract + os.environ.get("MAGI_EXTRA_CFLAGS", "").split()
+                    jobs.append((cmd, src, obj))
+                try:
+                    _build.compile_checked(jobs, verbose)          # (keeps each unit's ISA and runs the EXEC-prologue check on it, build.py)
+                except RuntimeError as e:
+                    raise RuntimeError("build for the traced drift failed:\n" + str(e)) from None
                 tmp = os.path.join(work, "libmagi_hip_user.so")
                 subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-Wl,-rpath,/opt/rocm/lib"])
                 os.replace(tmp, lib)                      # (the one publication: the name says which compiler built it)

@@ -81,3 +81,51 @@ def test_host_side_of_the_c_abi_is_clean_under_asan_and_ubsan():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sanitize_host.py")], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "sanitizer run clean" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+FAULTY_JOIN = """
+_Z6kernelv:
+	v_cmp_eq_u32_e32 vcc, 0, v60
+	s_and_saveexec_b64 s[2:3], vcc
+	s_cbranch_execz .LBB0_5
+; %bb.1:
+	s_getpc_b64 s[0:1]
+	s_swappc_b64 s[30:31], s[0:1]
+	ds_write_b64 v2, v[0:1] offset:13968
+.LBB0_5:                             ; %Flow
+	v_mov_b64_e32 v[100:101], v[32:33]
+	v_mov_b64_e32 v[98:99], v[28:29]
+	s_or_b64 exec, exec, s[2:3]
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+def test_exec_prologue_guard_flags_the_round3_miscompile_and_the_build_is_clean(tmp_path):
+    """Round 3's wrong energies (one-chain SIRW kernel) were hipcc placing live-range split copies of values that are live
+    in EVERY lane in front of the `s_or_b64 exec, exec, sN` of the join block behind `if (tid == 0) shs[4] = temperature(..)`: the copies
+    ran for lane 0 only.  magi_v2_amd.isa_check recognises that shape in the ISA; the build keeps every unit's ISA and fails (after one
+    retry without IPRA) when it appears.  Here: the checker on the faulty shape and on its repaired form, then on every unit of the
+    in-tree build."""
+    from magi_v2_amd import build, isa_check
+    bad = tmp_path / "bad.s"
+    bad.write_text(FAULTY_JOIN)
+    hits = isa_check.check_file(str(bad))
+    assert len(hits) == 1 and hits[0][1] == ".LBB0_5" and [i for _, i in hits[0][2]] == ["v_mov_b64_e32 v[100:101], v[32:33]", "v_mov_b64_e32 v[98:99], v[28:29]"]
+    good = tmp_path / "good.s"
+    lines = FAULTY_JOIN.split("\n")
+    k = next(i for i, l in enumerate(lines) if "s_or_b64 exec" in l)
+    lines.insert(k - 2, lines.pop(k))                          # the restore first, the copies behind it
+    good.write_text("\n".join(lines))
+    assert isa_check.check_file(str(good)) == []
+    spill = tmp_path / "spill.s"                               # SGPR spill lanes in front of the restore are harmless (they ignore EXEC)
+    spill.write_text(FAULTY_JOIN.replace("v_mov_b64_e32 v[100:101], v[32:33]", "v_readlane_b32 s2, v165, 4").replace("v_mov_b64_e32 v[98:99], v[28:29]", "v_readlane_b32 s3, v165, 5"))
+    assert isa_check.check_file(str(spill)) == []
+    build.build_lib(verbose=False)
+    n = 0
+    for src in build.sources():
+        isa = build.isa_path(os.path.join(build.HERE, "build", os.path.basename(src) + ".o"))
+        assert os.path.exists(isa), isa
+        assert isa_check.check_file(isa) == [], isa
+        n += 1
+    assert n >= 7
