@@ -228,6 +228,14 @@ int magi_sample(magi_handle* h, const magi_sampler_cfg* cfg, int n_chains,
 int magi_theta_init(magi_handle* h, int drift_id, int P, const double* Xhat, const double* mu, int num_iters, double learning_rate,
                     double* theta, double* loss_trace);
 
+/* ---- multi-GPU ---------------------------------------------------------------------------------
+ * There is deliberately NO magi_gather in this ABI (SURVEY 8b had listed one).  The path shards by independent (dataset, chain) units with
+ * no exchange while sampling (one handle per GPU, one process per GPU); its only collective is ONE gather of the post-burn-in samples at
+ * the end of a job, and that one lives where the job's process group already lives: magi_v2_amd/shard.py calls torch.distributed.gather
+ * (backend "nccl" = RCCL over xGMI) on the arrays magi_sampler_get_samples returned.  A C-side gather would have to bootstrap a second
+ * RCCL communicator (ncclGetUniqueId handed through the caller, ncclCommInitRank per handle) beside the one the host framework owns, for
+ * 52 MB per GPU once per job (< 1 ms over xGMI).  A binding in another host language gathers the same host arrays with its own collective. */
+
 /* ---- instrumentation (bench.py roofline leg) ----------------------------------------------- */
 
 /* Launch one gradient evaluation (the 3 mat-vec phases + reduce) `reps` times on the handle's

@@ -592,8 +592,14 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
     const bool use_graph = !h->opt.no_graph;
     if (use_graph && !h->graph_valid && (rc = build_graph(h))) return rc;
 
+    // (copies of this call ride on the handle's own non-blocking stream: a blocking hipMemcpy on the legacy stream is refused by HIP while ANOTHER
+    //  handle, driven from another host thread, is capturing its graph -- "would make the legacy stream depend on a capturing stream")
+    auto fetch = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream);
+        return e != hipSuccess ? e : hipStreamSynchronize(h->stream);
+    };
     std::vector<ChainCtl> ctl(h->n_chains);
-    MAGI_HIP_CHECK(h, hipMemcpy(ctl.data(), h->ch.ctl, sizeof(ChainCtl) * h->n_chains, hipMemcpyDeviceToHost));
+    MAGI_HIP_CHECK(h, fetch(ctl.data(), h->ch.ctl, sizeof(ChainCtl) * h->n_chains));
     long long lf0 = 0;
     int kmin = h->cfg.total;
     for (auto& c : ctl) { lf0 += c.total_leapfrogs; kmin = std::min(kmin, c.k); }
@@ -621,7 +627,7 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
     while (!done) {
         if (issued >= max_graphs && issued == retired) {
             (void)hipStreamSynchronize(h->stream);
-            (void)hipMemcpy(ctl.data(), h->ch.ctl, sizeof(ChainCtl) * h->n_chains, hipMemcpyDeviceToHost);
+            (void)fetch(ctl.data(), h->ch.ctl, sizeof(ChainCtl) * h->n_chains);
             std::string where;
             for (int i = 0; i < h->n_chains; ++i)
                 if (ctl[i].phase != PH_IDLE || ctl[i].k < g.stop_k) { where = " (chain " + std::to_string(i) + ": k=" + std::to_string(ctl[i].k) + ", phase=" + std::to_string(ctl[i].phase) + ", depth=" + std::to_string(ctl[i].depth) + ")"; break; }
@@ -652,7 +658,7 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
     MAGI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     {
         GlobalCtl gend{};
-        MAGI_HIP_CHECK(h, hipMemcpy(&gend, h->ch.gctl, sizeof(GlobalCtl), hipMemcpyDeviceToHost));
+        MAGI_HIP_CHECK(h, fetch(&gend, h->ch.gctl, sizeof(GlobalCtl)));
         h->last_slots = gend.slots;
         h->last_graphs = issued;
     }
@@ -662,7 +668,7 @@ int magi_sampler_run(magi_handle* h, int n_steps, int64_t* leapfrogs_done, doubl
         *kernel_ms = ms;
     }
     if (leapfrogs_done) {
-        MAGI_HIP_CHECK(h, hipMemcpy(ctl.data(), h->ch.ctl, sizeof(ChainCtl) * h->n_chains, hipMemcpyDeviceToHost));
+        MAGI_HIP_CHECK(h, fetch(ctl.data(), h->ch.ctl, sizeof(ChainCtl) * h->n_chains));
         long long lf1 = 0;
         for (auto& c : ctl) lf1 += c.total_leapfrogs;
         *leapfrogs_done = lf1 - lf0;

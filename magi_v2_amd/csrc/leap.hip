@@ -776,10 +776,13 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     //  the LDS counter too -- every wait for a tile would also wait for the staging traffic, and the ring would run one step deep)
     typedef double __attribute__((ext_vector_type(2))) d2v;
     typedef const d2v __attribute__((address_space(1))) * gd2_ptr;
-    const gd2_ptr A0 = (gd2_ptr)(unsigned long long)(reinterpret_cast<const double2*>(pb.tiles + (size_t)tile0 * TB * TB) + (size_t)(32 * wave + lj) * (TB / 2) + li);
-    const gd2_ptr A1 = (gd2_ptr)(unsigned long long)(reinterpret_cast<const double2*>(pb.tiles + (size_t)max(tile1, 0) * TB * TB) + (size_t)(32 * wave + lj) * (TB / 2) + li);
+    // Rows of a 16-row piece are dealt to the lanes as row = 4 lj + q (load instruction q fetches rows q, 4 + q, 8 + q, 12 + q: still four
+    // full 256-byte segments): a lane's four row-operand values of a piece are then FOUR CONSECUTIVE grid points = two 16-byte loads from
+    // the pair-interleaved mirror instead of four 8-byte ones (round 3 dealt row = 4 q + lj).
+    const gd2_ptr A0 = (gd2_ptr)(unsigned long long)(reinterpret_cast<const double2*>(pb.tiles + (size_t)tile0 * TB * TB) + (size_t)(32 * wave + 4 * lj) * (TB / 2) + li);
+    const gd2_ptr A1 = (gd2_ptr)(unsigned long long)(reinterpret_cast<const double2*>(pb.tiles + (size_t)max(tile1, 0) * TB * TB) + (size_t)(32 * wave + 4 * lj) * (TB / 2) + li);
     auto ld = [&](int s, int q) -> double2 {
-        const d2v v = ((s >> 3) ? A1 : A0)[(size_t)(16 * (s & 1) + 4 * q) * (TB / 2) + 16 * ((wave + ((s & 7) >> 1)) & 3)];
+        const d2v v = ((s >> 3) ? A1 : A0)[(size_t)(16 * (s & 1) + q) * (TB / 2) + 16 * ((wave + ((s & 7) >> 1)) & 3)];
         return double2{v.x, v.y};
     };
     // (The ring goes out FIRST, right behind the task descriptor, then the operand slices.  Device time stamps of a workgroup
@@ -805,7 +808,9 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     const int groups = (nch + 15) >> 4;
     typedef const double __attribute__((address_space(1))) * gd_ptr;
     typedef const char __attribute__((address_space(1))) * gc_ptr;
-    auto ldb = [](const double* sbase, unsigned boff) -> double { return *(gd_ptr)((gc_ptr)(unsigned long long)sbase + boff); };
+    // (16-byte loads from the pair-interleaved mirror, vop_elem: the prologue's ~30 vector-memory instructions per wave took 2.2-2.4 us to
+    //  ISSUE -- 240 of them on a CU, one address-processing pipe -- so their NUMBER is what counts: 12-16 now)
+    auto ld16 = [](const double* sbase, unsigned boff) -> double2 { const d2v v = *(gd2_ptr)((gc_ptr)(unsigned long long)sbase + boff); return double2{v.x, v.y}; };
     const double* mcol = ch.vop + vop_off(D, PLANES, pb.Np, groups, parity, (int)blockIdx.y, d, rowphi ? 1 + z : 0, bj * TB);     // (wave-uniform)
     const double* mcol1 = ch.vop + vop_off(D, PLANES, pb.Np, groups, parity, (int)blockIdx.y, d, rowphi1 ? 1 + z : 0, bj * TB);
     const double* mrow = ch.vop + vop_off(D, PLANES, pb.Np, groups, parity, (int)blockIdx.y, d, colphi ? 1 + z : 0, bi * TB);
@@ -813,19 +818,22 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
     double2 vv[4], vv1[4];
     double wf[2][4];
     {
-        const unsigned o = ((unsigned)(2 * (t >> 4)) * 16u + (unsigned)li) * 8u;
+        // column slice: point pair cp = (t >> 4) + 16 k of the block, column li: one 16-byte element of the mirror
+        const unsigned o = ((unsigned)(t >> 4) * 16u + (unsigned)li) * 16u;
+        const double2 zero2 = double2{0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            vv[k].x = (rowt && lcol) ? ldb(mcol, o + (unsigned)(32 * k) * 128u) : 0.0;
-            vv[k].y = (rowt && lcol) ? ldb(mcol, o + (unsigned)(32 * k + 1) * 128u) : 0.0;
-            vv1[k].x = (pair && lcol1) ? ldb(mcol1, o + (unsigned)(32 * k) * 128u) : 0.0;
-            vv1[k].y = (pair && lcol1) ? ldb(mcol1, o + (unsigned)(32 * k + 1) * 128u) : 0.0;
+            vv[k] = (rowt && lcol) ? ld16(mcol, o + (unsigned)(16 * k) * 256u) : zero2;
+            vv1[k] = (pair && lcol1) ? ld16(mcol1, o + (unsigned)(16 * k) * 256u) : zero2;
         }
-        const unsigned orow = ((unsigned)(32 * wave + lj) * 16u + (unsigned)li) * 8u;
+        // row slice: rows 32 wave + 16 cidx + 4 lj + q, q = 0 .. 3: point pairs (8 wave + 4 cidx + lj) 2 + {0, 1}
+        const unsigned orow = ((unsigned)(16 * wave + 2 * lj) * 16u + (unsigned)li) * 16u;
 #pragma unroll
-        for (int cidx = 0; cidx < 2; ++cidx)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wf[cidx][q] = (colt && lrow) ? ldb(mrow, orow + (unsigned)(16 * cidx + 4 * q) * 128u) : 0.0;
+        for (int cidx = 0; cidx < 2; ++cidx) {
+            const double2 w01 = (colt && lrow) ? ld16(mrow, orow + (unsigned)(8 * cidx) * 256u) : zero2;
+            const double2 w23 = (colt && lrow) ? ld16(mrow, orow + (unsigned)(8 * cidx + 1) * 256u) : zero2;
+            wf[cidx][0] = w01.x; wf[cidx][1] = w01.y; wf[cidx][2] = w23.x; wf[cidx][3] = w23.y;
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     SEP_STAMP(2);              // operand loads issued
@@ -896,7 +904,7 @@ void k_stream_sep(DevProblem pb, DevChains ch, SamplerCfgDev cfg, int parity) {
         double2 rb[4], rv[4];
         if (rowt) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(&stage[(4 * q + lj) * MC_PITCH + 2 * li]) = tt[q];
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(&stage[(4 * lj + q) * MC_PITCH + 2 * li]) = tt[q];      // (row of the piece = 4 lj + q)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 rb[q] = *reinterpret_cast<const double2*>(&stage[li * MC_PITCH + 2 * (4 * q + lj)]);
@@ -975,12 +983,12 @@ __global__ __launch_bounds__(256) void k_mirror(DevProblem pb, DevChains ch) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int dd = 0; dd < D; ++dd) {
-                double* m0 = ch.vop + vop_off(D, planes, pb.Np, groups, b, c >> 4, dd, 0, i);
-                m0[cl] = x[dd] - pb.mu[dd];
+                double* m0 = ch.vop + vop_off(D, planes, pb.Np, groups, b, c >> 4, dd, 0, 0);
+                m0[vop_elem(i, cl)] = x[dd] - pb.mu[dd];
 #pragma unroll
                 for (int k = 0; k < NBM; ++k)
                     if (k < DR::nbasis(dd))
-                        m0[(size_t)(cw == 8 ? 1 + (k >> 1) : 1 + k) * pb.Np * 16 + (cw == 8 ? (k & 1) * 8 + cl : cl)] = ph[dd][k];
+                        m0[(size_t)(cw == 8 ? 1 + (k >> 1) : 1 + k) * pb.Np * 16 + vop_elem(i, cw == 8 ? (k & 1) * 8 + cl : cl)] = ph[dd][k];
             }
     }
 }

@@ -221,43 +221,21 @@ __device__ __forceinline__ void point_block_sep(const DevProblem& pb, const DevC
     const bool fvalid = (t < 64) && (fd < D) && (fi < pb.N);
     typename GP::Ops ops;
     if (fvalid) ops = GP::load(pb, ch, lp, cc, fi, fd);
-    // product lanes: item = (slot, point); a thread has ceil(16 PST / 256) items (two for the built-in drifts), and the first eight block
-    // partials of ALL its items go out in one round -- item by item (round 3) the second item's loads waited for the first item's sum: one
-    // more memory round trip per launch.  The additions keep their order (slot order, batches of eight).
+    // product lanes: item = (slot, point); every used slot's nb block partials in flight together
     {
         const double* base = ch.tpart + (size_t)cc * PST * pb.nb * pb.Np;
-        constexpr int NIT = (PT_POINTS * PST + PT_THREADS - 1) / PT_THREADS;
-        double u0[NIT][8];
-        const double* srcv[NIT];
-        int s0v[NIT], s1v[NIT];
-        bool live[NIT];
 #pragma unroll
-        for (int q = 0; q < NIT; ++q) {
-            const int item = q * PT_THREADS + (int)t;
+        for (int it0 = 0; it0 < PT_POINTS * PST; it0 += PT_THREADS) {
+            const int item = it0 + (int)t;
             const int pt = item & (PT_POINTS - 1), slot = item / PT_POINTS;
             const int i = blk * PT_POINTS + pt;
-            live[q] = slot < PST && SL::slot_used(slot) && i < pb.N;
-            const int ic = min(i, pb.N - 1), sc = min(slot, PST - 1);
-            const int b = ic / TB;
-            s0v[q] = max(0, b - pb.wb); s1v[q] = min(pb.nb - 1, b + pb.wb);
-            srcv[q] = base + ((size_t)sc * pb.nb) * pb.Np + ic;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) u0[q][k] = live[q] ? srcv[q][(size_t)min(s0v[q] + k, s1v[q]) * pb.Np] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < NIT; ++q) {
-            const int item = q * PT_THREADS + (int)t;
-            const int pt = item & (PT_POINTS - 1), slot = item / PT_POINTS;
             if (slot < PST) {
                 double sum = 0.0;
-                if (live[q]) {
-                    const int s1 = s1v[q];
-                    const double* src = srcv[q];
-                    int sl = s0v[q];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) sum += (sl + k <= s1) ? u0[q][k] : 0.0;
-                    sl += 8;
-                    for (; sl + 7 <= s1; sl += 8) {         // (more than eight block partials per entry: N > 1024)
+                if (SL::slot_used(slot) && i < pb.N) {
+                    const int b = i / TB, s0 = max(0, b - pb.wb), s1 = min(pb.nb - 1, b + pb.wb);
+                    const double* src = base + ((size_t)slot * pb.nb) * pb.Np + i;
+                    int sl = s0;
+                    for (; sl + 7 <= s1; sl += 8) {
                         double u[8];
 #pragma unroll
                         for (int k = 0; k < 8; ++k) u[k] = src[(size_t)(sl + k) * pb.Np];
@@ -364,15 +342,15 @@ __device__ __forceinline__ void point_block_sep(const DevProblem& pb, const DevC
                 DR::basis(xq, ph);
                 const int cw = xop_width(ch.n_chains), groups = (ch.n_chains + 15) >> 4, cl = cc & 15;
                 const int planes = 1 + (NBM * cw + 15) / 16;
-                double* m0 = ch.vop + vop_off(D, planes, pb.Np, groups, mirror_buf, cc >> 4, fd, 0, fi);
-                m0[cl] = xn - s_mu[fd];
+                double* m0 = ch.vop + vop_off(D, planes, pb.Np, groups, mirror_buf, cc >> 4, fd, 0, 0);      // plane 0 of this component
+                m0[vop_elem(fi, cl)] = xn - s_mu[fd];
 #pragma unroll
                 for (int dd = 0; dd < D; ++dd) {
                     if (fd == dd) {
 #pragma unroll
                         for (int k = 0; k < NBM; ++k)
                             if (k < DR::nbasis(dd))
-                                m0[(size_t)(cw == 8 ? 1 + (k >> 1) : 1 + k) * pb.Np * 16 + (cw == 8 ? (k & 1) * 8 + cl : cl)] = ph[dd][k];
+                                m0[(size_t)(cw == 8 ? 1 + (k >> 1) : 1 + k) * pb.Np * 16 + vop_elem(fi, cw == 8 ? (k & 1) * 8 + cl : cl)] = ph[dd][k];
                     }
                 }
             }
@@ -505,15 +483,15 @@ __device__ __forceinline__ void boundary_block(const DevProblem& pb, const DevCh
                     DR::basis(xq, ph);
                     const int cw = xop_width(ch.n_chains), groups = (ch.n_chains + 15) >> 4, cl = cc & 15;
                     const int planes = 1 + (NBM * cw + 15) / 16;
-                    double* m0 = ch.vop + vop_off(D, planes, pb.Np, groups, mirror_buf, cc >> 4, fd, 0, fi);
-                    m0[cl] = xn_grid - s_mu[fd];
+                    double* m0 = ch.vop + vop_off(D, planes, pb.Np, groups, mirror_buf, cc >> 4, fd, 0, 0);
+                    m0[vop_elem(fi, cl)] = xn_grid - s_mu[fd];
 #pragma unroll
                     for (int dd = 0; dd < D; ++dd) {
                         if (fd == dd) {
 #pragma unroll
                             for (int k = 0; k < NBM; ++k)
                                 if (k < DR::nbasis(dd))
-                                    m0[(size_t)(cw == 8 ? 1 + (k >> 1) : 1 + k) * pb.Np * 16 + (cw == 8 ? (k & 1) * 8 + cl : cl)] = ph[dd][k];
+                                    m0[(size_t)(cw == 8 ? 1 + (k >> 1) : 1 + k) * pb.Np * 16 + vop_elem(fi, cw == 8 ? (k & 1) * 8 + cl : cl)] = ph[dd][k];
                         }
                     }
                 }

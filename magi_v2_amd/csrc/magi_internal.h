@@ -638,9 +638,12 @@ template <> struct DriftT<MAGI_DRIFT_SIRW> {
 // Storage of the separable streaming path (k_stream_sep, leap.hip).
 //   product slots of component d (tpart[chain][slot][other block][Np]; unused k stay zero):
 //       d PS + 0: hx = FH xc     + 1: ex = FE xc     + 2 + k: etf_k = FE^T phi_{d,k}     + 2 + NBMAX + k: kf_k = FK phi_{d,k}
-//   operand mirror vop[slot parity][chain group][d][plane][Np][16]: plane 0 = xc_d of the group's chains (column = chain & 15),
+//   operand mirror vop[slot parity][chain group][d][plane][Np / 2][16][2]: plane 0 = xc_d of the group's chains (column = chain & 15),
 //       plane 1 + z = basis group z: 16 matrix-core columns = (k, chain); with at most 8 chains (CW = 8) two basis functions share a
 //       plane (k = 2 z + (col >> 3), chain = col & 7), else one per plane (k = z, chain = col).  Entries never written stay zero.
+//       Inside a plane the grid points come in PAIRS: element (point i, column c) sits at vop_elem(i, c) = ((i >> 1) 16 + c) 2 + (i & 1), so
+//       that the two points a lane of the streaming kernel needs for one matrix-core operand register pair are ONE 16-byte load (round 4:
+//       the prologue of k_stream_sep is bound by the number of vector-memory instructions its CU has to issue, not by their latency).
 // ------------------------------------------------------------------------------------------
 template <int DRIFT> struct SepLayout {
     using DR = DriftT<DRIFT>;
@@ -659,9 +662,12 @@ template <int DRIFT> struct SepLayout {
     __host__ __device__ static constexpr int plane_of(int cw, int k) { return 1 + (cw == 8 ? (k >> 1) : k); }
     __host__ __device__ static constexpr int col_of(int cw, int k, int chain_local) { return cw == 8 ? ((k & 1) * 8 + chain_local) : chain_local; }
 };
+// start of the (even) point i's pair inside plane `plane` (i even: block starts are multiples of 128)
 __host__ __device__ inline size_t vop_off(int D, int planes, int Np, int groups, int b, int group, int d, int plane, int i) {
     return (((((size_t)b * groups + group) * D + d) * planes + plane) * (size_t)Np + i) * 16;
 }
+// element (point i, column c) relative to a plane's start
+__host__ __device__ inline size_t vop_elem(int i, int c) { return ((size_t)(i >> 1) * 16 + (size_t)c) * 2 + (size_t)(i & 1); }
 
 // ------------------------------------------------------------------------------------------
 // reductions: 64-lane butterfly, then a fixed-order sum over the block's waves (deterministic)

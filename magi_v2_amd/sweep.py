@@ -52,6 +52,7 @@ class SweepRunner:
         self.chains = chains_per_dataset
         self.units = shard_units(len(datasets), chains_per_dataset, rank, world)          # [(dataset index, [global unit ids])]
         self.engines, self.pbs, self.names = [], [], []
+        self._captured = False
         for ds, _ in self.units:
             name, pb = datasets[ds]
             eng = MagiEngine(device)
@@ -68,6 +69,7 @@ class SweepRunner:
             cfg = eng.default_cfg(**cfg_kw)
             rep = lambda v: np.repeat(np.asarray(v)[None], self.chains, axis=0)
             eng.sampler_init(cfg, rep(pb["Xhat"]), rep(pb["sig_pre0"]), rep(pb["th_pre0"]), seed=seed, chain_ids=ids)
+        self._captured = False
 
     def run(self, n_steps: int) -> int:
         """n_steps transitions of every chain of every owned dataset; returns the leapfrogs taken.  The handles are independent: each is
@@ -81,8 +83,12 @@ class SweepRunner:
             except BaseException as e:          # noqa: BLE001 (re-raised on the caller's thread)
                 err[k] = e
 
-        if len(self.engines) == 1:
-            work(0)
+        if len(self.engines) == 1 or not self._captured:
+            # (the first run after an initialisation captures each handle's leapfrog graph: a stream capture in one thread makes HIP refuse the
+            #  blocking copies of the other threads -- "would make the legacy stream depend on a capturing stream" -- so that run is sequential)
+            for k in range(len(self.engines)):
+                work(k)
+            self._captured = True
         else:
             ths = [threading.Thread(target=work, args=(k,)) for k in range(len(self.engines))]
             for t in ths:

@@ -36,6 +36,38 @@ void run(int wgs_per_cu, int iters) {
            ms * 1e6 / mfma_per_simd, 2048.0 * iters * CHAINS * 4 * grid / (ms * 1e-3) / 1e12);
     hipFree(out);
 }
+// v_mfma_f64_4x4x4_4b_f64: four independent 4 x 4 x 4 blocks per instruction (512 flop; accumulator = one double per lane).  Round 4: is its
+// rate per flop that of the 16 x 16 x 4 form?  Then products with only 8 live columns (8 chains: xc operands) could fill their instructions.
+template <int CHAINS>
+__global__ __launch_bounds__(256) void k4(double* out, int iters) {
+    double acc[CHAINS];
+    for (int c = 0; c < CHAINS; ++c) acc[c] = 0.0;
+    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(acc[c]) : "v"(a), "v"(b));
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    double s = 0.0;
+    for (int c = 0; c < CHAINS; ++c) s += acc[c];
+    if (s == 12345.678) out[0] = s;
+}
+template <int CHAINS>
+void run4(int wgs_per_cu, int iters) {
+    double* out; (void)hipMalloc(&out, 8);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int grid = 256 * wgs_per_cu;
+    hipLaunchKernelGGL(k4<CHAINS>, dim3(grid), dim3(256), 0, 0, out, iters);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(k4<CHAINS>, dim3(grid), dim3(256), 0, 0, out, iters);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double mfma_per_simd = (double)iters * CHAINS * wgs_per_cu;
+    printf("4x4x4_4b chains %d  waves/SIMD %d: %.1f us  -> %.1f ns per MFMA per SIMD, %.1f TFLOP/s\n", CHAINS, wgs_per_cu, ms * 1e3,
+           ms * 1e6 / mfma_per_simd, 512.0 * iters * CHAINS * 4 * grid / (ms * 1e-3) / 1e12);
+    (void)hipFree(out);
+}
 // VALU: v_fma_f64 on 8 independent accumulators per lane
 __global__ __launch_bounds__(256) void kv(double* out, int iters) {
     double acc[8];
@@ -66,5 +98,6 @@ void run_valu(int wgs_per_cu, int iters) {
 int main() {
     for (int w = 1; w <= 3; ++w) { run<1>(w, 4096); run<2>(w, 2048); run<4>(w, 1024); run<8>(w, 512); run<16>(w, 256); }
     for (int w = 1; w <= 3; ++w) run_valu(w, 65536);
+    for (int w = 1; w <= 2; ++w) { run4<1>(w, 8192); run4<4>(w, 2048); run4<16>(w, 512); }
     return 0;
 }
