@@ -15,7 +15,7 @@ One rank per GPU (torchrun); chains are independent (no data-path collective); t
 are gathered once to rank 0 over RCCL after the timed region.
 
 After the headline region a one-GPU run (N = 1) also measures, untimed-setup style, the single-GPU figures of the other
-BASELINE configs -- config 1 (SEIR-4, N = 161, b = 80, one chain, 200 + 200 NUTS steps, next to the torch-CPU leg),
+BASELINE configs -- config 1 (SEIR-4, N = 161, b = 80, one chain, 200 + 200 NUTS steps, next to the C-port CPU leg),
 config 3's per-GPU share (8 chains, N = 1024), one dataset of config 4's alpha sweep (8 chains, N = 161, b = 80) and
 config 5 (N = 8192 x 4: one pooled build with per-class device times, and the streaming kernel on 4.4 GB of operator
 blocks) -- plus the hyper-parameter fit's ms per Adam step -- and reports them as FLAT scalars inside `roofline`
@@ -61,7 +61,7 @@ def parse():
                     help="DIAGNOSTIC ONLY: every rank samples the chain ids of rank 0 (identical per-GPU work, bit-identical "
                          "chains).  The default gives every chain of the job its own Philox stream -- independent chains, as "
                          "BASELINE config 3 asks -- so the max-over-ranks time includes the NUTS tree-size spread between chains")
-    ap.add_argument("--cpu-threads", type=str, default="1,8,32,all", help="thread counts of the torch-CPU baseline leg")
+    ap.add_argument("--cpu-threads", type=str, default="1,8,32,all", help="thread counts of the CPU baseline legs")
     ap.add_argument("--profile-slots", type=int, default=512, help="leapfrog slots of the in-sampler kernel-duration leg")
     ap.add_argument("--config", choices=["headline", "alpha-sweep"], default="headline",
                     help="headline: BASELINE configs[1] / configs[2] (see --chains-per-gpu).  alpha-sweep: BASELINE configs[3] -- the ten alpha-sweep "
@@ -98,14 +98,18 @@ def timed_run(eng, cfg, pb, n_chains, chain_ids, seed, burnin, warmup, steps):
     return el, lf, dev_ms, slots
 
 
-def cpu_gradient_rates(pb, mats, band, drift, P, state, threads, max_seconds):
-    """torch-CPU fp64 restatement of magi_v2.py:308-348 (oracle/torch_cpu.py): value+gradient evaluations per second per thread count."""
+def cpu_gradient_rates(pb, mats, band, drift, P, state, threads, max_seconds, leg="c", min_evals=400):
+    """Value+gradient evaluations per second per thread count of a CPU restatement of magi_v2.py:308-348: leg "c" = oracle/logpost_c.c
+    (C + OpenMP, analytic gradient, each matrix read once per product pair), leg "torch" = oracle/torch_cpu.py (bmm + autograd)."""
     from oracle import magi_oracle as orc
-    from oracle import torch_cpu
     C_inv, m, K_inv = mats
     pr = orc.Problem(I=pb["I"], mu=pb["mu"], C_inv=orc.band_part(C_inv, band), m=orc.band_part(m, band), K_inv=orc.band_part(K_inv, band),
                      N_ds=pb["N_ds"], obs_idx=pb["idx"], y=pb["y"], beta=pb["beta"], LB=pb["LB"], drift=drift, P=P)
     Xc, spc, tpc = state
+    if leg == "c":
+        from oracle import logpost_c
+        return pr, logpost_c.time_gradients(pr, Xc, spc, tpc, threads, min_evals=min_evals, max_seconds=max_seconds)
+    from oracle import torch_cpu
     return pr, torch_cpu.time_gradients(pr, Xc, spc, tpc, threads, min_evals=200, max_seconds=max_seconds)
 
 
@@ -376,9 +380,10 @@ def main():
     except (OSError, KeyError, ValueError, StopIteration):
         pass
 
-    # ---- CPU baseline: torch-CPU fp64 restatement of magi_v2.py:308-348 (bmm + autograd, what XLA-CPU executes for
-    #      the reference), timed at several thread counts on this host; samples/s = gradient evaluations/s over the leapfrogs
-    #      per sample the GPU chain needed in the timed region.  Second leg: the numpy oracle continuing the SAME chain. ----
+    # ---- CPU baseline: the C + OpenMP restatement of magi_v2.py:308-348 (oracle/logpost_c.c), timed at several thread
+    #      counts on this host; samples/s = gradient evaluations/s over the leapfrogs per sample the GPU chain needed in the timed
+    #      region.  Second leg: the torch-CPU restatement (bmm + autograd, what XLA-CPU executes for the reference).  Third leg: the
+    #      numpy oracle continuing the SAME chain. ----
     cpu = None
     ncpu = os.cpu_count() or 1
     threads = sorted({min(ncpu, ncpu if t == "all" else int(t)) for t in a.cpu_threads.split(",")})
@@ -392,13 +397,20 @@ def main():
         from oracle import magi_oracle as orc
         import threadpoolctl
         Xc, spc, tpc, ss, bc = state
-        pr, rates = cpu_gradient_rates(pb, mats, band, "seir4", P, (Xc[0], spc[0], tpc[0]), threads, 6.0)
+        pr, rates = cpu_gradient_rates(pb, mats, band, "seir4", P, (Xc[0], spc[0], tpc[0]), threads, 4.0, leg="c")
         best_t = max(rates, key=rates.get)
+        t_threads = sorted({t for t in threads if t in (8, 32)} or {threads[-1]})
+        _, t_rates = cpu_gradient_rates(pb, mats, band, "seir4", P, (Xc[0], spc[0], tpc[0]), t_threads, 4.0, leg="torch")
         cpu = {"value": round(rates[best_t] / lf_per_sample, 5), "unit": "samples/s", "cores": best_t, "kind": "port",
-               "sample": f">= 200 value+gradient evaluations (or 6 s) per thread count of oracle/torch_cpu.py -- torch-CPU fp64 bmm + autograd "
-                         f"restatement of magi_v2.py:308-348 -- at the GPU chain's state; converted with the {lf_per_sample:.1f} leapfrogs per "
-                         "sample of the timed GPU region",
+               "sample": f">= 400 value+gradient evaluations (or 4 s) per thread count of oracle/logpost_c.c -- C + OpenMP restatement of "
+                         f"magi_v2.py:308-348 with the analytic gradient, dense matrices as the reference multiplies them, each read once per "
+                         f"product pair -- at the GPU chain's state; converted with the {lf_per_sample:.1f} leapfrogs per sample of the timed "
+                         "GPU region; the best thread count is reported",
                "gradient_evals_per_s": {str(t): round(r, 2) for t, r in rates.items()}, "leapfrogs_per_s": round(rates[best_t], 2),
+               "torch_leg": {"gradient_evals_per_s": {str(t): round(r, 2) for t, r in t_rates.items()},
+                             "samples_per_s": round(max(t_rates.values()) / lf_per_sample, 5),
+                             "sample": "oracle/torch_cpu.py (fp64 bmm + autograd, the shape of what XLA-CPU executes for the reference): "
+                                       ">= 200 evaluations or 4 s per thread count"},
                "host_cpus": ncpu, "cpu_model": cpu_model}
         # second leg: the numpy oracle (restated TFP NUTS) continues the same chain for a few transitions
         q = orc.pack(Xc[0], spc[0], tpc[0])
@@ -469,7 +481,7 @@ def main():
     if extra_note:
         out["extra_configs"] = extra_note
     if cpu:
-        out["speedup_vs_cpu_port"] = round(value / cpu["value"], 1)          # against the BEST thread count of the torch-CPU leg
+        out["speedup_vs_cpu_port"] = round(value / cpu["value"], 1)          # against the BEST thread count of the C + OpenMP leg
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -519,12 +531,12 @@ def extra_configs(a, eng, host, MagiEngine, pb2, roofline, threads, dev_index):
                      "cfg1_us_per_slot": round(el1 / max(slots1, 1) * 1e6, 3), "cfg1_leapfrogs_per_sample": round(lf1 / 200, 1)})
     if not a.no_cpu_baseline:
         st = e1.sampler_state()
-        _, r1 = cpu_gradient_rates(pb1, mats1, 80, "seir4", P, (st[0][0], st[1][0], st[2][0]), [t for t in threads if t <= 8] or [1], 3.0)
+        _, r1 = cpu_gradient_rates(pb1, mats1, 80, "seir4", P, (st[0][0], st[1][0], st[2][0]), [t for t in threads if t <= 8] or [1], 3.0, min_evals=20000)
         bt = max(r1, key=r1.get)
         roofline.update({"cfg1_cpu_samples_per_s": round(r1[bt] / max(lf1 / 200, 1e-9), 3), "cfg1_cpu_cores": bt,
                          "cfg1_cpu_gradient_evals_per_s": round(r1[bt], 1),
                          "cfg1_speedup_vs_cpu_port": round((200 / el1) / (r1[bt] / max(lf1 / 200, 1e-9)), 1)})
-    note["config1"] = "SEIR-4 N=161 (tests/golden/g3_pipeline.npz: the vignette thinning of data/SEIR_seed=0.csv), b=80, 1 chain, 200 burn-in + 200 timed NUTS samples, reference defaults; CPU: torch-CPU gradient rate / leapfrogs per sample"
+    note["config1"] = "SEIR-4 N=161 (tests/golden/g3_pipeline.npz: the vignette thinning of data/SEIR_seed=0.csv), b=80, 1 chain, 200 burn-in + 200 timed NUTS samples, reference defaults; CPU: gradient rate of oracle/logpost_c.c (best of <= 8 threads) / leapfrogs per sample"
 
     # ---- config 4: one dataset of the alpha sweep (alpha = 0.15, seed 0) x 8 chains, N = 161, b = 80 ----
     sweep = np.load(os.path.join(ROOT, "tests", "golden", "seir_alpha_sweep.npz"))

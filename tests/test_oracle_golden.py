@@ -149,6 +149,60 @@ def test_torch_cpu_leg_matches_g4(golden_dir, tag):
             np.testing.assert_allclose(got, want, rtol=0, atol=1e-10 * np.abs(want).max())
 
 
+@pytest.mark.parametrize("tag", ["seir3_N161", "seir4_N81", "sirw_N41"])
+def test_c_port_matches_g4(golden_dir, tag):
+    """oracle/logpost_c.c (the C/OpenMP restatement bench.py times as the CPU baseline) against the G4 records, with 1 and with 3 threads
+    (the transposed products are accumulated per thread: the sum order depends on the thread count, the result within rounding does not)."""
+    from oracle import logpost_c
+    g = _load(golden_dir, f"g4_logpost_{tag}.npz")
+    probs = {}
+    for r in range(0, len(g["rec_logp"]), 2):
+        b = int(g["rec_band"][r])
+        if b not in probs:
+            probs[b] = problem_from_g4(g, None if b < 0 else b)
+        si = int(g["rec_state"][r])
+        for threads in (1, 3):
+            lp, terms, gX, gs, gt = logpost_c.logpost_grad(g["state_X"][si], g["state_sig_pre"][si], g["state_th_pre"][si], float(g["rec_temp"][r]), probs[b], threads)
+            # (t1 = x^T C^-1 x cancels over entries of C^-1 that are 1e6 times its size: the row sums here are FMA + SIMD partial sums,
+            #  TF's and numpy's are library dots -- 1.2e-12 observed on the vignette's t1, hence 1e-11 where the numpy oracle has 1e-12)
+            np.testing.assert_allclose(terms, g["rec_terms"][r], rtol=1e-11)
+            assert abs(lp - g["rec_logp"][r]) <= 1e-11 * abs(g["rec_logp"][r])
+            for got, want in ((gX, g["rec_gX"][r]), (gs, g["rec_gsig"][r]), (gt, g["rec_gth"][r])):
+                np.testing.assert_allclose(got, want, rtol=0, atol=1e-10 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("drift", ["seir3", "seir4", "sirw"])
+def test_c_port_matches_the_numpy_oracle(drift):
+    """Non-symmetric random matrices, an odd grid size and ragged observations: the C restatement and the numpy oracle are the same function
+    (the G4 matrices are symmetric up to rounding, so a transposed product in the wrong place would pass G4 and fail here)."""
+    from oracle import logpost_c
+    rng = np.random.default_rng(11)
+    _, D, P = orc.DRIFTS[drift]
+    N = 97
+    A = lambda: rng.standard_normal((D, N, N)) * 0.3
+    idx = np.sort(rng.choice(N * D, 61, replace=False))
+    pr = orc.Problem(I=np.linspace(0, 1, N), mu=rng.standard_normal(D), C_inv=A(), m=A(), K_inv=A(), N_ds=np.bincount(idx % D, minlength=D).astype(float),
+                     obs_idx=idx, y=rng.standard_normal(61), beta=1.7, LB=np.full(D, 1e-3), drift=drift, P=P)
+    X, sp, tp = rng.random((N, D)), rng.standard_normal(D), rng.standard_normal(P)
+    want = orc.logpost_grad(X, sp, tp, 0.7, pr)
+    t_want = orc.logpost_terms(X, sp, tp, pr)
+    for threads in (1, 4):
+        lp, terms, gX, gs, gt = logpost_c.logpost_grad(X, sp, tp, 0.7, pr, threads)
+        assert abs(lp - want[0]) <= 1e-13 * abs(want[0])
+        np.testing.assert_allclose(terms, t_want[:4], rtol=1e-12)
+        for got, w in ((gX, want[1]), (gs, want[2]), (gt, want[3])):
+            np.testing.assert_allclose(got, w, rtol=0, atol=1e-12 * np.abs(w).max())
+    # a drift whose (D, P) does not match the matrices is refused, not read out of bounds
+    other = {"seir3": "seir4", "seir4": "seir3", "sirw": "seir3"}[drift]
+    a = logpost_c._Args(pr, X, sp, tp)
+    head = list(a.head); head[3] = orc.DRIFT_IDS[other]
+    import ctypes
+    out = [np.zeros(k) for k in (4, N * D, D, P)]
+    lp_ = ctypes.c_double()
+    rc = logpost_c.load().magi_oracle_c_logpost_grad(*head, 1.0, 1, ctypes.byref(lp_), *[o.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) for o in out])
+    assert rc == -1
+
+
 def test_vignette_beta_constant(golden_dir):
     g = _load(golden_dir, "g4_logpost_seir3_N161.npz")
     # SURVEY section 8a4: beta = D*|I|/sum(N_d) = 3*161/243 for the vignette
