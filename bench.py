@@ -61,7 +61,7 @@ def parse():
                     help="DIAGNOSTIC ONLY: every rank samples the chain ids of rank 0 (identical per-GPU work, bit-identical "
                          "chains).  The default gives every chain of the job its own Philox stream -- independent chains, as "
                          "BASELINE config 3 asks -- so the max-over-ranks time includes the NUTS tree-size spread between chains")
-    ap.add_argument("--cpu-threads", type=str, default="1,8,32,all", help="thread counts of the CPU baseline legs")
+    ap.add_argument("--cpu-threads", type=str, default="1,8,16,32,64,all", help="thread counts of the CPU baseline legs")
     ap.add_argument("--profile-slots", type=int, default=512, help="leapfrog slots of the in-sampler kernel-duration leg")
     ap.add_argument("--config", choices=["headline", "alpha-sweep"], default="headline",
                     help="headline: BASELINE configs[1] / configs[2] (see --chains-per-gpu).  alpha-sweep: BASELINE configs[3] -- the ten alpha-sweep "
@@ -96,6 +96,22 @@ def timed_run(eng, cfg, pb, n_chains, chain_ids, seed, burnin, warmup, steps):
     el = time.perf_counter() - t0
     slots, _ = eng.sampler_run_stats()
     return el, lf, dev_ms, slots
+
+
+def cpu_quota():
+    """CPU bandwidth limit of this process's cgroup in cores (cgroup v2 cpu.max, v1 cfs quota), or None when unlimited / unknown."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, p = fh.read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+            q, p = float(fq.read()), float(fp.read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_gradient_rates(pb, mats, band, drift, P, state, threads, max_seconds, leg="c", min_evals=400):
@@ -386,7 +402,9 @@ def main():
     #      numpy oracle continuing the SAME chain. ----
     cpu = None
     ncpu = os.cpu_count() or 1
-    threads = sorted({min(ncpu, ncpu if t == "all" else int(t)) for t in a.cpu_threads.split(",")})
+    quota = cpu_quota()
+    usable = int(min(ncpu, len(os.sched_getaffinity(0)), max(1.0, 2 * quota) if quota else ncpu))       # (OpenMP barriers spin: far past the quota they stall)
+    threads = sorted({min(usable, usable if t == "all" else int(t)) for t in a.cpu_threads.split(",")})
     try:
         with open("/proc/cpuinfo") as fh:
             cpu_model = next(l.split(":", 1)[1].strip() for l in fh if l.startswith("model name"))
@@ -411,7 +429,7 @@ def main():
                              "samples_per_s": round(max(t_rates.values()) / lf_per_sample, 5),
                              "sample": "oracle/torch_cpu.py (fp64 bmm + autograd, the shape of what XLA-CPU executes for the reference): "
                                        ">= 200 evaluations or 4 s per thread count"},
-               "host_cpus": ncpu, "cpu_model": cpu_model}
+               "host_cpus": ncpu, "host_cpu_quota": quota, "cpu_model": cpu_model}
         # second leg: the numpy oracle (restated TFP NUTS) continues the same chain for a few transitions
         q = orc.pack(Xc[0], spc[0], tpc[0])
         fn_L = orc.make_fn_L(pr)
@@ -562,6 +580,7 @@ def extra_configs(a, eng, host, MagiEngine, pb2, roofline, threads, dev_index):
     tb = time.perf_counter()
     e5.build_matrices(I5, pb5["hp"]["phi1s"], pb5["hp"]["phi2s"], 2.01, want_host=False)
     build_s = time.perf_counter() - tb
+    pw = e5.build_profile()["potrf_wall"]                           # the two factorisations of THAT build as a whole (look-ahead on), device clock
     e5.set_option("build_profile", 1)
     e5.build_matrices(I5, pb5["hp"]["phi1s"], pb5["hp"]["phi2s"], 2.01, want_host=False)
     prof = e5.build_profile()
@@ -575,7 +594,8 @@ def extra_configs(a, eng, host, MagiEngine, pb2, roofline, threads, dev_index):
     prod_ms = ms("m_K_products")
     roofline.update({
         "n8192_build_s": round(build_s, 4), "n8192_build_frac": round(alg / build_s / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
-        "n8192_potrf_ms": round(potrf_ms, 2), "n8192_potrf_frac": round(potrf_flop / (potrf_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+        "n8192_potrf_ms": round(pw[1], 2), "n8192_potrf_frac": round(potrf_flop / (pw[1] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+        "n8192_potrf_serialised_ms": round(potrf_ms, 2), "n8192_potrf_serialised_frac": round(potrf_flop / (potrf_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
         "n8192_products_ms": round(prod_ms, 2), "n8192_products_frac": round(fl("m_K_products") / (prod_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
         "n8192_operators_frac": round(fl("single_phase_operators") / (ms("single_phase_operators") * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
         "n8192_trtri_frac": round(fl("trtri") / (ms("trtri") * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
@@ -593,7 +613,8 @@ def extra_configs(a, eng, host, MagiEngine, pb2, roofline, threads, dev_index):
                      "n8192_read_only_frac": round((b5[4] - 2.0 * 128 * 8 * (b5[4] / (128 * 128 * 8.0 + 2.0 * 128 * 8.0))) / (ph5[7] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                      "n8192_logpost_finite": bool(np.isfinite(lp5))})
     note["config5"] = ("N=8192 x 4 dense: second pooled build timed on the host clock (n8192_build_s; 5 N^3 D algorithmic flops), a third build with "
-                       "MAGI_BUILD_PROFILE=1 for the per-class device times (serialised: HIP events around every launch), then the streaming kernel "
+                       "the per-class profile on (serialised: HIP events around every launch, look-ahead of the factorisations off: n8192_potrf_serialised_*; "
+                       "n8192_potrf_ms / _frac are the two factorisations of the SECOND build as a whole, device clock, look-ahead on), then the streaming kernel "
                        "on the 4.4 GB of operator blocks (standalone, 20 launches: nothing is cache-resident at this size)")
     e5.close()
 

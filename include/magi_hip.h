@@ -273,7 +273,7 @@ int magi_stream_kernel_name(magi_handle* h, int n_chains, char* buf, int cap);
  * MAGI_SEP_PAIR_MIN, MAGI_FUSED_PARITY, MAGI_GEMM_REMAP_MIN, MAGI_POTRF_PANELS, MAGI_NO_GRAPH, MAGI_FIT_HOST_LOOP,
  * MAGI_FIT_PER_COMPONENT, MAGI_BUILD_PROFILE, MAGI_BUILD_SERIAL are read ONCE, by magi_create; afterwards only this call
  * changes an option (no getenv on a compute path).  Names: "stream_family" (0 auto, 1 mc, 2 valu; takes effect at the next
- * magi_sampler_init / log-posterior call), "sep_pair_min" (next packing), "fused_parity", "gemm_remap_min", "potrf_panels",
+ * magi_sampler_init / log-posterior call), "sep_pair_min" (next packing), "fused_parity", "gemm_remap_min", "potrf_panels", "potrf_lookahead_min",
  * "no_graph", "fit_host_loop", "fit_per_component", "build_profile", "build_serial", and the test hook
  * "slot_budget_graphs" (cap on the graph launches of one magi_sampler_run; 0 = the computed bound; no environment variable). */
 int magi_set_option(magi_handle* h, const char* name, int64_t value);
@@ -281,8 +281,12 @@ int magi_set_option(magi_handle* h, const char* name, int64_t value);
 /* Diagnostics: per-class device time of the last magi_build_matrices run with option "build_profile" set
  * (HIP events around every launch; the build is serialised while profiling).
  * Classes, in order: matern, diag-block Cholesky+inverse, potrf panel, potrf trailing SYRK, trtri,
- * T^T T, m / K products, single-phase operators.  flops = fp64 operations actually issued.  Returns the
- * number of classes (8); arrays must hold at least that many entries. */
+ * T^T T, m / K products, single-phase operators.  flops = fp64 operations actually issued.  One more row follows the
+ * classes and is filled by EVERY dense build of the handle, profiled or not: "potrf_wall" = the two blocked Cholesky
+ * factorisations as a whole on the device clock (ms; flops = N^3 / 3 per matrix) -- the only figure that shows the
+ * look-ahead of the factorisation (option "potrf_lookahead_min": grids from that size on fork their rank-k updates
+ * to a second, CU-masked stream; 0 = never), which the serialising per-launch profile switches off.  Returns the
+ * number of rows (9); arrays must hold at least 16 entries. */
 int magi_build_profile(magi_handle* h, double* flops, double* ms, int64_t* calls);
 
 /* Diagnostics: the 64-double transformed-parameter block of a chain (softplus / sigmoid / log

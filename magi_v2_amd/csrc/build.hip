@@ -851,6 +851,7 @@ struct Linalg {
     long bs_dinv = 0, bs_panel = 0;
     int* status = nullptr;      // [batch][2]
     bool pooled = false;        // dinv / panel belong to the handle's work space
+    bool lookahead = false;     // potrf may fork the rank-k updates to the handle's CU-masked stream (dense build only; never inside a capture)
 };
 
 // optional per-class timing of the build (MAGI_BUILD_PROFILE=1): HIP events around every launch, so the
@@ -910,12 +911,41 @@ int launch_gemm(magi_handle* h, hipStream_t s, const GemmArgs& g_in, int batch =
 }
 
 // In-place lower Cholesky of the la.batch matrices A + z la.bsA (N x N row-major, ld = N), all of them in every launch.
-// Right-looking over block columns of 512 = four 128-wide panels, left-looking inside a block column: the 128 x 128 diagonal
-// blocks are factorised AND inverted by k_diag_chol_inv (one workgroup per component), a panel is solved as a GEMM with that
-// inverse, panel c of a block column first takes the rank-128c update of the panels before it (a tall 128-wide GEMM), and the
-// trailing matrix takes all four panels in ONE rank-512 SYRK update on the matrix cores -- four times the flops per byte of the
-// trailing matrix's read-modify-write of a rank-128 sweep.
+// Right-looking over block columns of 128 * opt.potrf_panels (384 = three 128-wide panels by default), left-looking inside a block
+// column: the 128 x 128 diagonal blocks are factorised AND inverted by k_diag_chol_inv (one workgroup per component), a panel is
+// solved as a GEMM with that inverse, panel c of a block column first takes the rank-128c update of the panels before it (a tall
+// 128-wide GEMM), and the trailing matrix takes all the block column's panels in ONE rank-384 SYRK update on the matrix cores --
+// three times the flops per byte of the trailing matrix's read-modify-write of a rank-128 sweep (four and more panels: fewer
+// bytes still, but a tile of the update then lives longer than the chain's launches it shares the CUs with under look-ahead).
 // The inverses of the diagonal blocks stay in la.dinv for the triangular inverse that follows.
+// The handle's second stream for the look-ahead of potrf: its hardware queue may use every CU except the first one of each XCD
+// (CU-mask bit b names CU b / 8 of XCD b % 8 on this part: tools/micro/cumask.hip), plus the two fork / join events.  nullptr when
+// such a stream cannot be had (the factorisation then runs on one stream, as for small grids).
+hipStream_t magi_trail_stream(magi_handle* h) {
+    if (h->stream_trail) return h->stream_trail;
+    if (h->trail_unavailable) return nullptr;
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || ncu < 64 || ncu % 8) { h->trail_unavailable = true; return nullptr; }
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int c = 8; c < ncu; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
+    hipStream_t st = nullptr, sc = nullptr;
+    int pr_lo = 0, pr_hi = 0;
+    bool ok = hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi) == hipSuccess && hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) == hipSuccess &&
+              hipStreamCreateWithPriority(&sc, hipStreamNonBlocking, pr_hi) == hipSuccess;
+    for (int i = 0; i < 3 && ok; ++i) ok = hipEventCreateWithFlags(&h->ev_la[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        if (st) (void)hipStreamDestroy(st);
+        if (sc) (void)hipStreamDestroy(sc);
+        for (int i = 0; i < 3; ++i) { if (h->ev_la[i]) (void)hipEventDestroy(h->ev_la[i]); h->ev_la[i] = nullptr; }
+        h->trail_unavailable = true;
+        return nullptr;
+    }
+    h->stream_chain = sc;
+    h->stream_trail = st;
+    return st;
+}
+
 int potrf_status(Linalg& la, const char* what, int status_slot = 0) {
     magi_handle* h = la.h;
     std::vector<int> st((size_t)2 * la.batch, -1);
@@ -934,13 +964,14 @@ int potrf(Linalg& la, double* A, const char* what, bool defer_status = false, in
     magi_handle* h = la.h;
     const int N = la.N, NB = 128;
     const size_t lds = (size_t)DG_LDS_DOUBLES * sizeof(double);
+    hipStream_t sc = la.s;                      // the stream of the block columns' chains (look-ahead: the handle's high-priority stream)
     for (int z = 0; z < la.batch; ++z)          // status words of this slot <- -1
         MAGI_HIP_CHECK(h, hipMemsetAsync(la.status + 2 * z + status_slot, 0xFF, sizeof(int), la.s));
     auto diag = [&](int j0, int n) {
-        prof_begin(la.s);
-        hipLaunchKernelGGL(k_diag_chol_inv, dim3(la.batch), dim3(256), lds, la.s, A + (size_t)j0 * N + j0, (long)N, n,
+        prof_begin(sc);
+        hipLaunchKernelGGL(k_diag_chol_inv, dim3(la.batch), dim3(256), lds, sc, A + (size_t)j0 * N + j0, (long)N, n,
                            la.dinv + (size_t)(j0 / NB) * 128 * 128, la.status + status_slot, j0, la.bsA, la.bs_dinv, 2);
-        prof_end(la.s, BC_DIAG, (double)n * n * n * la.batch);        // n^3/3 factor + 2 n^3/3 inverse
+        prof_end(sc, BC_DIAG, (double)n * n * n * la.batch);        // n^3/3 factor + 2 n^3/3 inverse
     };
     auto panel = [&](int jblk, int j0, int n, int row0) -> int {     // rows >= row0 of block column j0 <- . Linv_jj^T
         (void)jblk;
@@ -950,11 +981,11 @@ int potrf(Linalg& la, double* A, const char* what, bool defer_status = false, in
         g.B = la.dinv + (size_t)(j0 / NB) * 128 * 128; g.sBn = 128; g.sBk = 1;
         g.C = P; g.ldc = N; g.M = N - row0; g.N = n; g.K = n; g.alpha = 1.0; g.beta = 0.0;
         g.batchA = la.bsA; g.batchB = la.bs_dinv; g.batchC = la.bsA;
-        return launch_gemm(h, la.s, g, la.batch, BC_PANEL);
+        return launch_gemm(h, sc, g, la.batch, BC_PANEL);
     };
     // (a transposed copy of the panels, so that this update reads both operands along their unit-stride dimension, was measured:
     //  no gain -- 34.6 against 34.1 ms at N = 8192 -- the rank-k updates are bound by the tall thin launches inside a block column)
-    auto syrk = [&](int row0, int ncols, int k0, int K) -> int {     // A[row0.., row0 .. row0 + ncols) -= A[row0.., k0 .. k0+K) A[row0 .. row0+ncols, k0 .. k0+K)^T (lower tiles)
+    auto syrk = [&](hipStream_t st, int row0, int ncols, int k0, int K) -> int {     // A[row0.., row0 .. row0 + ncols) -= A[row0.., k0 .. k0+K) A[row0 .. row0+ncols, k0 .. k0+K)^T (lower tiles)
         GemmArgs t{};
         double* P = A + (size_t)row0 * N + k0;
         t.A = P; t.sAm = N; t.sAk = 1;
@@ -962,27 +993,61 @@ int potrf(Linalg& la, double* A, const char* what, bool defer_status = false, in
         t.C = A + (size_t)row0 * N + row0; t.ldc = N; t.M = N - row0; t.N = ncols; t.K = K; t.alpha = -1.0; t.beta = 1.0;
         t.lower_only = ncols > GT ? 1 : 0;          // (a single tile column has no tile above the diagonal)
         t.batchA = la.bsA; t.batchB = la.bsA; t.batchC = la.bsA;
-        return launch_gemm(h, la.s, t, la.batch, BC_TRAIL);
+        return launch_gemm(h, st, t, la.batch, BC_TRAIL);
     };
     // outer block column = NPAN panels of 128 (left-looking inside it: panel c first takes the rank-128c update of the panels
-    // before it), then ONE rank-(128 NPAN) update of the trailing matrix.
-    // (Look-ahead -- the rest of a trailing update on a second stream under the next block column's diagonal / panel chain -- was
-    //  measured: 347 against 345 ms at N = 8192.  The update's workgroups hold every CU's LDS, and the diagonal kernel needs 158 KB
-    //  of one CU: it does not start before the update drains.)
+    // before it), then the rank-(128 NPAN) update of the trailing matrix.
+    //
+    // Look-ahead (grids of opt.potrf_lookahead_min points and more, dense build only): the update is split by columns into U1 = the
+    // NEXT block column (all the chain of that column needs) and U2 = the rest, and U2 goes to a second stream while this stream
+    // continues with U1 and the next column's chain of tall updates / diagonal blocks / panels:
+    //     this stream :  chain(J) | wait U2(J-1) | U1(J) | chain(J+1) | wait U2(J) | U1(J+1) ...
+    //     second one  :            ... U2(J-1)   | wait chain(J) | U2(J) ...
+    // A plain second stream gains nothing (measured in round 3: 347 against 345 ms): the update's workgroups hold every CU's
+    // registers and LDS, the diagonal kernel needs 158 KB of ONE CU's LDS and does not start before the update has drained.  The
+    // second stream is therefore created with a CU mask that leaves out one CU of every XCD (magi_trail_stream;
+    // tools/micro/cumask.hip: a 158 KB workgroup then starts within 10-20 us beside a kernel that fills the masked queue, against
+    // "when that kernel ends" without the mask): the update loses 8 of 256 CUs, the diagonal kernel always finds a home.
     const int NPAN = std::max(1, std::min(h->opt.potrf_panels, 16));
+    const int W = NPAN * NB;
+    hipStream_t s2 = nullptr;
+    if (la.lookahead && !g_prof.on && h->opt.potrf_lookahead_min > 0 && N >= h->opt.potrf_lookahead_min && N > 2 * W) s2 = magi_trail_stream(h);
+    if (s2) {           // fork: the chains continue on the high-priority stream (their short launches then win the CUs an update's workgroups free)
+        MAGI_HIP_CHECK(h, hipEventRecord(h->ev_la[2], la.s));
+        MAGI_HIP_CHECK(h, hipStreamWaitEvent(h->stream_chain, h->ev_la[2], 0));
+        MAGI_HIP_CHECK(h, hipStreamWaitEvent(s2, h->ev_la[2], 0));
+        sc = h->stream_chain;
+    }
+    bool u2_pending = false;
     int rc = MAGI_OK;
-    for (int j0 = 0; j0 < N && rc == MAGI_OK; j0 += NPAN * NB) {
+    for (int j0 = 0; j0 < N && rc == MAGI_OK; j0 += W) {
         for (int c = 0; c < NPAN && rc == MAGI_OK; ++c) {
             const int jc = j0 + c * NB;
             if (jc >= N) break;
             const int nc = std::min(NB, N - jc);
-            if (c > 0 && (rc = syrk(jc, nc, j0, c * NB))) break;
+            if (c > 0 && (rc = syrk(sc, jc, nc, j0, c * NB))) break;
             diag(jc, nc);
             if (jc + NB < N) rc = panel(j0, jc, nc, jc + NB);
         }
-        const int jn = j0 + NPAN * NB;
+        const int jn = j0 + W;
         if (rc || jn >= N) break;
-        rc = syrk(jn, N - jn, j0, NPAN * NB);
+        if (!s2) { rc = syrk(sc, jn, N - jn, j0, W); continue; }
+        const int w1 = std::min(W, N - jn);
+        MAGI_HIP_CHECK(h, hipEventRecord(h->ev_la[0], sc));                                     // chain(J) done
+        if (u2_pending) MAGI_HIP_CHECK(h, hipStreamWaitEvent(sc, h->ev_la[1], 0));             // U1(J) touches what U2(J-1) updated
+        u2_pending = false;
+        if (jn + w1 < N) {
+            MAGI_HIP_CHECK(h, hipStreamWaitEvent(s2, h->ev_la[0], 0));
+            if ((rc = syrk(s2, jn + w1, N - jn - w1, j0, W))) break;
+            MAGI_HIP_CHECK(h, hipEventRecord(h->ev_la[1], s2));
+            u2_pending = true;
+        }
+        rc = syrk(sc, jn, w1, j0, W);
+    }
+    if (s2) {           // join (also on an error path: nothing is left on the side streams unobserved)
+        if (u2_pending) MAGI_HIP_CHECK(h, hipStreamWaitEvent(sc, h->ev_la[1], 0));
+        MAGI_HIP_CHECK(h, hipEventRecord(h->ev_la[2], sc));
+        MAGI_HIP_CHECK(h, hipStreamWaitEvent(la.s, h->ev_la[2], 0));
     }
     if (rc) return rc;
     hipError_t e = hipGetLastError();
@@ -1475,9 +1540,11 @@ int magi_matern_blocks_device(magi_handle* h, const double* I, int N, double phi
     return MAGI_OK;
 }
 
-int magi_build_profile_get(double* flops, double* ms, long* calls) {
+int magi_build_profile_get(const magi_handle* h, double* flops, double* ms, long* calls) {
     for (int i = 0; i < BC_COUNT; ++i) { flops[i] = g_prof.flops[i]; ms[i] = g_prof.ms[i]; calls[i] = g_prof.calls[i]; }
-    return BC_COUNT;
+    // one more row, filled by EVERY dense build of this handle: its two factorisations as a whole (N^3 / 3 flops per matrix)
+    flops[BC_COUNT] = h ? h->potrf_wall_flops : 0.0; ms[BC_COUNT] = h ? h->potrf_wall_ms : 0.0; calls[BC_COUNT] = h && h->potrf_wall_ms > 0.0 ? 2 : 0;
+    return BC_COUNT + 1;
 }
 
 int magi_ensure_dense(magi_handle* h, int N, int D) {
@@ -1534,6 +1601,10 @@ int magi_build_dense_device(magi_handle* h, const double* I, int N, int D, int n
     if (!Kap.p || !P.p || !PP.p) return MAGI_E_HIP;
     Linalg la{};
     int rc = linalg_init(la, h, N, B, (long)nn, true);
+    la.lookahead = true;
+    for (int i = 0; i < 4 && rc == MAGI_OK; ++i)
+        if (!h->ev_pw[i] && hipEventCreate(&h->ev_pw[i]) != hipSuccess) rc = magi_fail(h, MAGI_E_HIP, "build: event");
+    h->potrf_wall_ms = 0.0; h->potrf_wall_flops = 0.0;
     std::vector<int> status((size_t)2 * n_sel, -1);
     for (int d0 = 0; d0 < n_sel && rc == MAGI_OK;) {
         int nb = 1;
@@ -1545,7 +1616,9 @@ int magi_build_dense_device(magi_handle* h, const double* I, int N, int D, int n
         double* Md = h->dDense[1] + nn * sel[d0];
         double* Kd = h->dDense[2] + nn * sel[d0];
         // Kappa = L L^T, T = L^-1, C^-1 = Kappa^-1 = T^T T   (Kappa is consumed)            magi_v2.py:818, 126
+        if (!rc) (void)hipEventRecord(h->ev_pw[0], la.s);
         if (!rc) rc = potrf(la, Kap.p, "Kappa", true, 0);
+        if (!rc) (void)hipEventRecord(h->ev_pw[1], la.s);
         if (!rc) rc = trtri(la, Kap.p);
         if (!rc) rc = lauum_tt(la, Kap.p, Cd, (long)nn);
         // Wt = (p_Kappa T^T)^T = T p_Kappa^T = -T p_Kappa   (p_Kappa is exactly antisymmetric: the sign of s - t is its only odd
@@ -1581,12 +1654,21 @@ int magi_build_dense_device(magi_handle* h, const double* I, int N, int D, int n
             rc = launch_gemm(h, la.s, g, nb);
         }
         // K^-1                                                                                magi_v2.py:128
+        if (!rc) (void)hipEventRecord(h->ev_pw[2], la.s);
         if (!rc) rc = potrf(la, PP.p, "K_d", true, 1);
+        if (!rc) (void)hipEventRecord(h->ev_pw[3], la.s);
         if (!rc) rc = trtri(la, PP.p);
         if (!rc) rc = lauum_tt(la, PP.p, Kd, (long)nn);
         if (!rc && hipMemcpyAsync(&status[(size_t)2 * d0], la.status, (size_t)2 * nb * sizeof(int), hipMemcpyDeviceToHost, la.s) != hipSuccess)
             rc = magi_fail(h, MAGI_E_HIP, "build: status readback");
         if (!rc && hipStreamSynchronize(la.s) != hipSuccess) rc = magi_fail(h, MAGI_E_HIP, "build: synchronize");
+        if (!rc) {      // whole factorisations on the device clock (with the per-launch profile on they are serialised, like everything else)
+            float a = 0.f, b = 0.f;
+            if (hipEventElapsedTime(&a, h->ev_pw[0], h->ev_pw[1]) == hipSuccess && hipEventElapsedTime(&b, h->ev_pw[2], h->ev_pw[3]) == hipSuccess) {
+                h->potrf_wall_ms += (double)a + (double)b;
+                h->potrf_wall_flops += 2.0 * nb * ((double)N * N * N / 3.0);
+            }
+        }
         d0 += nb;
     }
     linalg_free(la);

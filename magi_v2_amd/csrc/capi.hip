@@ -115,6 +115,7 @@ void magi_options_from_env(MagiOptions& o) {
     o.fused_parity = num("MAGI_FUSED_PARITY", 0) == 1;
     o.gemm_remap_min = (int)num("MAGI_GEMM_REMAP_MIN", o.gemm_remap_min);
     o.potrf_panels = (int)num("MAGI_POTRF_PANELS", o.potrf_panels);
+    o.potrf_lookahead_min = (int)num("MAGI_POTRF_LOOKAHEAD_MIN", o.potrf_lookahead_min);
     o.no_graph = getenv("MAGI_NO_GRAPH") != nullptr;
     o.fit_host_loop = getenv("MAGI_FIT_HOST_LOOP") != nullptr;
     o.fit_per_component = getenv("MAGI_FIT_PER_COMPONENT") != nullptr;
@@ -247,6 +248,10 @@ void magi_destroy(magi_handle* h) {
     if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
     if (h->h_gctl) (void)hipHostFree(h->h_gctl);
     if (h->apply_pin) (void)hipHostFree(h->apply_pin);
+    for (int i = 0; i < 3; ++i) if (h->ev_la[i]) (void)hipEventDestroy(h->ev_la[i]);
+    if (h->stream_chain) (void)hipStreamDestroy(h->stream_chain);
+    for (int i = 0; i < 4; ++i) if (h->ev_pw[i]) (void)hipEventDestroy(h->ev_pw[i]);
+    if (h->stream_trail) (void)hipStreamDestroy(h->stream_trail);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -887,6 +892,7 @@ int magi_set_option(magi_handle* h, const char* name, int64_t value) {
     else if (k == "sep_pair_min") o.sep_pair_min = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
     else if (k == "fused_parity") o.fused_parity = value == 1;
     else if (k == "gemm_remap_min") o.gemm_remap_min = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
+    else if (k == "potrf_lookahead_min") { if (value < 0) return magi_fail(h, MAGI_E_BADARG, "potrf_lookahead_min >= 0"); o.potrf_lookahead_min = (int)value; }
     else if (k == "potrf_panels") { if (value < 1 || value > 16) return magi_fail(h, MAGI_E_BADARG, "potrf_panels in [1, 16]"); o.potrf_panels = (int)value; }
     else if (k == "slot_budget_graphs") o.slot_budget_graphs = std::max<int64_t>(0, value);
     else if (k == "no_graph") o.no_graph = value != 0;
@@ -901,7 +907,7 @@ int magi_set_option(magi_handle* h, const char* name, int64_t value) {
 int magi_build_profile(magi_handle* h, double* flops, double* ms, int64_t* calls) {
     if (!h || !flops || !ms || !calls) return MAGI_E_BADARG;
     long c[16];
-    const int n = magi_build_profile_get(flops, ms, c);
+    const int n = magi_build_profile_get(h, flops, ms, c);
     for (int i = 0; i < n; ++i) calls[i] = c[i];
     return n;
 }

@@ -848,7 +848,8 @@ struct MagiOptions {
     int sep_pair_min = 256;             // pack.hip: pair the diagonal blocks FH_bb + FK_bb when there are more tasks than this
     int fused_parity = 0;               // magi_logpost_grad_fused evaluates as an even (0) / odd (1) leapfrog slot
     int gemm_remap_min = 24;            // build.hip: super-block tile order from this many super-blocks per launch
-    int potrf_panels = 4;               // build.hip: 128-wide panels per block column of the Cholesky factorisation
+    int potrf_panels = 3;               // build.hip: 128-wide panels per block column of the Cholesky factorisation (3: best of 2..8 at N = 1024..8192, profiles/r04_potrf_lookahead_ab.txt)
+    int potrf_lookahead_min = 4096;     // build.hip: grids from this size on factorise with look-ahead (0: never), see potrf
     long long slot_budget_graphs = 0;   // TEST HOOK: cap on the graph launches of one magi_sampler_run (0 = the computed bound)
     int no_graph = 0;                   // launch the leapfrog slots directly (debugging, long rocprofv3 kernel traces)
     int fit_host_loop = 0, fit_per_component = 0;      // build.hip: A/B paths of the hyper-parameter fit
@@ -907,6 +908,13 @@ struct magi_handle {
     hipEvent_t prof_e0 = nullptr, prof_e1 = nullptr;
     long long last_slots = 0, last_graphs = 0;      // of the last magi_sampler_run
     double* apply_pin = nullptr;     // pinned staging of magi_dense_apply (V | Y)
+    // look-ahead of the blocked Cholesky (build.hip: potrf): a second stream whose queue may NOT use one CU of every XCD -- the
+    // rank-k updates it carries leave those CUs to the diagonal-block kernel of the next block column -- and the fork / join events
+    hipStream_t stream_trail = nullptr, stream_chain = nullptr;      // (the chain of a block column runs on a stream of the highest priority)
+    hipEvent_t ev_la[3] = {nullptr, nullptr, nullptr};
+    bool trail_unavailable = false;  // the masked stream could not be created: factorise without look-ahead
+    hipEvent_t ev_pw[4] = {nullptr, nullptr, nullptr, nullptr};      // begin / end of the two factorisations of a dense build
+    double potrf_wall_ms = 0.0, potrf_wall_flops = 0.0;              // of the last dense build (whole factorisations, not serialised)
     size_t apply_pin_cap = 0;
 };
 
@@ -935,7 +943,7 @@ int magi_launch_point(magi_handle* h, int n_chains, int parity, hipStream_t s); 
 int magi_launch_leap_finalize(magi_handle* h, int n_chains, double* d_out, hipStream_t s, int parity = 0);
 int magi_leap_wgs(const DevProblem& pb);
 bool magi_stream_family_mc(const magi_handle* h, int n_chains);        // leap.hip
-int magi_build_profile_get(double* flops, double* ms, long* calls);           // build.hip
+int magi_build_profile_get(const magi_handle* h, double* flops, double* ms, long* calls);           // build.hip
 int magi_fit_hparams_device(magi_handle* h, const double* I, int N, int D, const double* X, const double* mu, const double* mu_phi2,
                             const double* sd_phi2, const double* sig_loc, double nu, int iters, double lr, double jitter,
                             double* phi1, double* phi2, double* sig2, double* loss_trace);

@@ -406,10 +406,11 @@ class MagiEngine:
         return total.value, ph
 
     BUILD_CLASSES = ("matern", "diag_chol_inv", "potrf_panel", "potrf_trailing_syrk", "trtri", "TtT", "m_K_products",
-                     "single_phase_operators")
+                     "single_phase_operators", "potrf_wall")
 
     def build_profile(self):
-        """Per-class (flops, ms, calls) of the last build_matrices run with set_option("build_profile", 1)."""
+        """Per-class (flops, ms, calls) of the last build_matrices run with set_option("build_profile", 1); the last row, "potrf_wall", is
+        filled by every build: its two Cholesky factorisations as a whole (look-ahead included when the build was not profiled)."""
         f, ms = np.zeros(16), np.zeros(16)
         calls = np.zeros(16, dtype=np.int64)
         n = self._lib.magi_build_profile(self._h, _ptr(f), _ptr(ms), calls.ctypes.data_as(_lp))

@@ -147,15 +147,17 @@ class _env:
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("N,remap,panels", [(1024, None, None), (2048, None, None), (2048, 1, 2), (2048, 1, 8)],
-                         ids=["1024", "2048", "2048-remap-2panels", "2048-remap-8panels"])
-def test_full_size_inverse_properties(N, remap, panels):
+@pytest.mark.parametrize("N,remap,panels,lookahead", [(1024, None, None, None), (2048, None, None, None), (2048, 1, 2, None), (2048, 1, 8, None), (2048, None, None, 1024),
+                                                      (2048, 1, 4, 1024)],
+                         ids=["1024", "2048", "2048-remap-2panels", "2048-remap-8panels", "2048-lookahead", "2048-remap-4panels-lookahead"])
+def test_full_size_inverse_properties(N, remap, panels, lookahead):
     """C^-1 Kappa = I, m Kappa = p_Kappa and K^-1 K_ref = I on random columns at BASELINE sizes; K_ref = Kappa_pp +
     p_Kappa Kappa^-1 p_Kappa is formed on the host from the GPU's Matern blocks (pinned against mpmath at small N).
     K^-1 is the worst-conditioned product of the build: Schur complement, second Cholesky, second inverse.
     remap / panels: the XCD-aware super-block tile order forced on every GEMM launch (it switches on by itself only above
-    N = 4096) and 2 / 8 panels per potrf block column instead of 4 -- the code paths of the N = 8192 build at a size where
-    the dense host truth is affordable."""
+    N = 4096), 2 / 4 / 8 panels per potrf block column instead of 3, and the factorisation's look-ahead (rank-k updates forked to the
+    CU-masked side stream, on by itself from N = 4096) -- the code paths of the N = 8192 build at a size where the dense host truth is
+    affordable."""
     from magi_v2_amd.engine import MagiEngine
     EPS = np.finfo(float).eps
     I = np.arange(N) * 0.025
@@ -164,6 +166,8 @@ def test_full_size_inverse_properties(N, remap, panels):
         eng.set_option("gemm_remap_min", remap)
     if panels is not None:
         eng.set_option("potrf_panels", panels)
+    if lookahead is not None:
+        eng.set_option("potrf_lookahead_min", lookahead)
     C_inv, m, K_inv = eng.build_matrices(I, [0.05], [0.1], 2.01)
     Kap, pK, Kpp = eng.matern_blocks(I, 0.05, 0.1, 2.01)
     cols = np.random.default_rng(0).integers(0, N, 16)
@@ -215,6 +219,32 @@ def test_remapped_tile_order_is_bit_identical_n2048():
     for a, b, what in zip(plain, forced, ("C_inv", "m", "K_inv", "logp", "gX", "gsig", "gth")):
         np.testing.assert_array_equal(np.asarray(a), np.asarray(b), err_msg=what)
     assert np.isfinite(plain[3]) and np.abs(plain[0]).max() > 0
+
+
+def test_lookahead_factorisation_is_bit_identical_n2048():
+    """Look-ahead of the blocked Cholesky (csrc/build.hip: potrf -- the rank-k update right of the next block column runs on a second,
+    CU-masked stream under the next column's chain) reorders launches, never a tile's arithmetic or the order of the updates a tile
+    takes: with it forced on at N = 2048 (four components, different hyper-parameters; 3 and 4 panels per block column) every dense
+    output equals the one-stream build bit for bit.  A missing event between the two streams would show up here as a tile that missed
+    an update or took it twice; the one-stream build is held to dense host truth by test_full_size_inverse_properties[2048]."""
+    from magi_v2_amd.engine import MagiEngine
+    N = 2048
+    I, X_obs, truth, th = host.synthetic_seir(N, seed=0)
+    hp = host.hparams_initial(host.linear_interpolate(X_obs))
+    for panels in (3, 4):
+        outs = []
+        eng = MagiEngine(0)
+        eng.set_option("potrf_panels", panels)
+        for la_min in (0, 1024, 1024):                   # (twice with look-ahead: the second build reuses streams and events)
+            eng.set_option("potrf_lookahead_min", la_min)
+            outs.append(eng.build_matrices(I, hp["phi1s"], hp["phi2s"], 2.01))
+            wall = eng.build_profile()["potrf_wall"]     # (flops, ms, calls) of the two factorisations as a whole
+            assert wall[1] > 0.0 and wall[2] == 2 and wall[0] == pytest.approx(2 * 4 * N ** 3 / 3.0, rel=1e-12)
+        eng.close()
+        for later in outs[1:]:
+            for a, b, what in zip(outs[0], later, ("C_inv", "m", "K_inv")):
+                np.testing.assert_array_equal(a, b, err_msg=f"{what}, {panels} panels")
+        assert np.abs(outs[0][2]).max() > 0
 
 
 def test_config5_build_outputs_against_matern_columns():

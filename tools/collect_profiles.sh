@@ -17,9 +17,14 @@ MAGI_GRAPH_SLOTS=2 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format 
 MAGI_GRAPH_SLOTS=2 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 1 --warmup 0 --burnin 12 --no-cpu-baseline --no-extra-configs --profile-slots 2 > $O/pmc_write.log 2>&1 || exit 1
 MAGI_GRAPH_SLOTS=2 timeout -k 10 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -- python3 bench.py --steps 1 --warmup 0 --burnin 12 --no-cpu-baseline --no-extra-configs --profile-slots 2 > $O/pmc_l2.log 2>&1; echo "l2 rc=$?" >> $O/kt_graph64.rc
 # 4. BASELINE config 5: N = 8192 x 4 matrix build -- kernel trace (per-class kernel names), per-class profile, GEMM counters
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_build8k -- python3 tools/exp_build_once.py 8192 3 > $O/kt_build8k.log 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_build8k -- python3 tools/exp_build_once.py 8192 3 nola > $O/kt_build8k.log 2>&1 || exit 1
 MAGI_BUILD_PROFILE=1 timeout -k 10 200 python3 tools/exp_build_profile.py 8192 > $O/build_profile_n8192.json 2> $O/build_profile.err || exit 1
-python3 tools/potrf_trace_summary.py $(ls $O/kt_build8k/*/*kernel_trace.csv | head -1) 8192 4 > $O/potrf_rank_k_by_launch.txt 2>&1
+python3 tools/potrf_trace_summary.py $(ls $O/kt_build8k/*/*kernel_trace.csv | head -1) 8192 4 3 > $O/potrf_rank_k_by_launch.txt 2>&1
+# the factorisation with look-ahead: A/B on the device clock, and who overlaps whom (kernel trace of a build with look-ahead on)
+timeout -k 10 300 python3 tools/exp_potrf_lookahead.py 8192 3 > $O/potrf_lookahead_ab.txt 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/kt_build8k_la -- python3 tools/exp_build_once.py 8192 2 > $O/kt_build8k_la.log 2>&1 || exit 1
+python3 tools/potrf_timeline.py $(ls $O/kt_build8k_la/*/*kernel_trace.csv | head -1) 120 > $O/potrf_lookahead_timeline.txt 2>&1
+rm -rf $O/kt_build8k_la
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $O/pmc_gemm -- python3 tools/exp_build_once.py 8192 > $O/pmc_gemm.log 2>&1 || exit 1
 # 5. micro; the matrix-core streaming kernel by chain count; the 8-chain sampler's kernel durations on the graph path
 timeout -k 5 60 tools/micro/mfma_rate > $O/micro_mfma_rate.txt 2>&1

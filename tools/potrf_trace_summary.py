@@ -1,12 +1,14 @@
 """Dev: where the blocked Cholesky's rank-k updates spend their time, launch by launch (BASELINE config 5).
     rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 tools/exp_build_once.py 8192 2
-    python tools/potrf_trace_summary.py DIR/*/*kernel_trace.csv 8192 4
+    python tools/potrf_trace_summary.py DIR/*/*kernel_trace.csv 8192 4 [panels per block column, default 3]
+(run the traced build with MAGI_POTRF_LOOKAHEAD_MIN=0: with look-ahead a trailing update is two launches on two streams)
 The rank-k class (k_gemm_f64<3>) holds two kinds of launch: the TRAILING update of a block column (lower tiles of the whole trailing
 matrix, K = 512) and the TALL 128-wide updates inside a block column (K = 128 / 256 / 384).  The trace tells them apart by grid size;
 flops per launch follow from the launch order (csrc/build.hip: potrf)."""
 import csv, sys
 import numpy as np
 path, N, D = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+NPAN_ARG = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 rows = [r for r in csv.DictReader(open(path))]
 t = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 rk = [r for r in rows if "k_gemm_f64<3" in r["Kernel_Name"]]
@@ -15,8 +17,8 @@ pan = [t(r) for r in rows if "k_gemm_f64<2" in r["Kernel_Name"]]
 nbuild = max(1, len(diag) // (2 * (N // 128)))
 grid = np.array([int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) // max(1, int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 256)))) for r in rk])
 dur = np.array([t(r) for r in rk])
-# expected launch sequence of one factorisation: per block column j0 (4 panels): tall K = 128, 256, 384; then the trailing update
-NB, NPAN = 128, 4
+# expected launch sequence of one factorisation: per block column j0 (NPAN panels): tall K = 128, 256, ...; then the trailing update
+NB, NPAN = 128, NPAN_ARG
 seq = []
 for j0 in range(0, N, NPAN * NB):
     for c in range(1, NPAN):
