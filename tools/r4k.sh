@@ -1,3 +1,7 @@
-mkdir -p gpurun_out/r4k
-for n in 1024 2048 4096; do for p in 3 4; do timeout -k 10 300 python tools/exp_potrf_lookahead.py $n 3 $p > gpurun_out/r4k/ab_n${n}_p$p.txt 2>&1 || exit 1; done; done
-for f in gpurun_out/r4k/ab_n*; do head -3 $f; done
+mkdir -p gpurun_out/r4n
+timeout -k 10 300 python tools/exp_potrf_lookahead.py 8192 3 3 > gpurun_out/r4n/ab_p3.txt 2>&1 && \
+timeout -k 10 300 python tools/exp_potrf_lookahead.py 8192 3 4 > gpurun_out/r4n/ab_p4.txt 2>&1 && \
+timeout -k 10 300 python tools/exp_potrf_lookahead.py 4096 3 3 > gpurun_out/r4n/ab_n4096.txt 2>&1 && \
+timeout -k 10 300 python tools/exp_potrf_lookahead.py 1024 3 3 > gpurun_out/r4n/ab_n1024.txt 2>&1 && \
+timeout -k 10 300 python tools/exp_potrf_lookahead.py 2048 3 3 > gpurun_out/r4n/ab_n2048.txt 2>&1
+cat gpurun_out/r4n/ab_*.txt
