@@ -584,6 +584,7 @@ def extra_configs(a, eng, host, MagiEngine, pb2, roofline, threads, dev_index):
     e5.set_option("build_profile", 1)
     e5.build_matrices(I5, pb5["hp"]["phi1s"], pb5["hp"]["phi2s"], 2.01, want_host=False)
     prof = e5.build_profile()
+    prof.pop("potrf_wall")                                          # (in the serialised build it repeats three of the classes)
     e5.set_option("build_profile", 0)
     fl = lambda k: prof[k][0]
     ms = lambda k: prof[k][1]

@@ -9,12 +9,13 @@ from magi_v2_amd import host
 from magi_v2_amd.engine import MagiEngine
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-panels = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+panels = int(sys.argv[3]) if len(sys.argv) > 3 else None
 I, X_obs, truth, th = host.synthetic_seir(N, seed=0)
 hp = host.hparams_initial(host.linear_interpolate(X_obs))
 eng = MagiEngine(0)
-eng.set_option("potrf_panels", panels)
-print(f"N = {N}, {panels} panels of 128 per block column")
+if panels is not None:
+    eng.set_option("potrf_panels", panels)
+print(f"N = {N}, {panels if panels is not None else 'the default (3)'} panels of 128 per block column")
 eng.build_matrices(I, hp["phi1s"], hp["phi2s"], 2.01, want_host=False)
 sums = {}
 for name, la_min in (("one stream", 0), ("look-ahead", 2048), ("one stream", 0), ("look-ahead", 2048)):
