@@ -233,7 +233,7 @@ def main():
 
     from magi_v2_amd import host
     from magi_v2_amd.engine import MagiEngine
-    from magi_v2_amd.shard import chain_ids_for_rank, gather_samples
+    from magi_v2_amd.shard import chain_ids_for_rank, family_chains_for, gather_samples
 
     N, D, P = a.grid, 4, 3
     cpg = a.chains_per_gpu
@@ -259,6 +259,7 @@ def main():
     rep = lambda v: np.repeat(np.asarray(v)[None], cpg, axis=0)
     unit_ids = chain_ids_for_rank(rank, world, cpg * world)              # which (dataset, chain) units this rank owns
     chain_ids = list(range(cpg)) if a.replicate_chains else unit_ids     # the Philox streams they are sampled with
+    eng.set_option("family_chains", family_chains_for(cpg * world, world))      # (one kernel family on every rank; a no-op for this even shard)
     eng.sampler_init(cfg, rep(pb["Xhat"]), rep(pb["sig_pre0"]), rep(pb["th_pre0"]), seed=a.seed, chain_ids=chain_ids)
     eng.sampler_run(a.burnin)
     if a.warmup > 0:

@@ -270,10 +270,12 @@ int magi_gradient_bytes(magi_handle* h, int n_chains, double* phase_bytes);
 int magi_stream_kernel_name(magi_handle* h, int n_chains, char* buf, int cap);
 
 /* Tuning / test switches of a handle (csrc/magi_internal.h: MagiOptions).  The environment variables MAGI_STREAM_FAMILY,
- * MAGI_SEP_PAIR_MIN, MAGI_FUSED_PARITY, MAGI_GEMM_REMAP_MIN, MAGI_POTRF_PANELS, MAGI_NO_GRAPH, MAGI_FIT_HOST_LOOP,
+ * MAGI_FAMILY_CHAINS, MAGI_SEP_PAIR_MIN, MAGI_FUSED_PARITY, MAGI_GEMM_REMAP_MIN, MAGI_POTRF_PANELS, MAGI_NO_GRAPH, MAGI_FIT_HOST_LOOP,
  * MAGI_FIT_PER_COMPONENT, MAGI_BUILD_PROFILE, MAGI_BUILD_SERIAL are read ONCE, by magi_create; afterwards only this call
  * changes an option (no getenv on a compute path).  Names: "stream_family" (0 auto, 1 mc, 2 valu; takes effect at the next
- * magi_sampler_init / log-posterior call), "sep_pair_min" (next packing), "fused_parity", "gemm_remap_min", "potrf_panels", "potrf_lookahead_min",
+ * magi_sampler_init / log-posterior call), "family_chains" (> 0: "auto" chooses the kernel family as if the batch had this many chains -- a
+ * sharded job passes its largest per-GPU share on every rank, so that a chain's samples do not depend on how many chains share its GPU),
+ * "sep_pair_min" (next packing), "fused_parity", "gemm_remap_min", "potrf_panels", "potrf_lookahead_min",
  * "no_graph", "fit_host_loop", "fit_per_component", "build_profile", "build_serial", and the test hook
  * "slot_budget_graphs" (cap on the graph launches of one magi_sampler_run; 0 = the computed bound; no environment variable). */
 int magi_set_option(magi_handle* h, const char* name, int64_t value);

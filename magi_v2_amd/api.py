@@ -332,9 +332,11 @@ class MAGI_v2:
     # ------------------------------------------------------------------------------------------
     def predict(self, num_results: int = 1000, num_burnin_steps: int = 1000, sigma_sqs_LB=None, verbose=False, *,
                 n_chains: int = 1, seed: Optional[int] = None, chain_ids: Optional[Sequence[int]] = None,
-                stale_cache: bool = True, anneal: bool = True, max_tree_depth: int = 10, step_size: float = 0.1):
+                stale_cache: bool = True, anneal: bool = True, max_tree_depth: int = 10, step_size: float = 0.1,
+                family_chains: Optional[int] = None):
         """magi_v2.py:286-425.  Returns the reference's results dictionary; with n_chains > 1 every
-        sample array gains a leading chain axis."""
+        sample array gains a leading chain axis.  ``family_chains``: in a job sharded over GPUs, the largest per-GPU share
+        (shard.family_chains_for) -- every rank then samples with the same kernel family whatever its own share."""
         assert ~np.any(np.isnan(self.Xhat_init)), "Please make sure Xhat_init does not have NaNs."
         assert ~np.any(np.isnan(self.sigma_sqs_init)), "Please make sure sigma_sqs_init does not have NaNs."
         assert ~np.any(np.isnan(self.thetas_init)), "Please make sure thetas_init does not have NaNs."
@@ -344,6 +346,8 @@ class MAGI_v2:
         sigma_sqs_LB = np.asarray(sigma_sqs_LB, dtype=np.float64)
         eng = self.engine
         self._sync_matrices()
+        if family_chains is not None:
+            eng.set_option("family_chains", int(family_chains))
         eng.set_problem(self.mu_ds, self.N_ds.astype(np.float64), np.asarray(self.not_nan_idxs),
                         np.asarray(self.y_tau_ds_observed), float(self.beta), sigma_sqs_LB, self.drift)
         sig_pre0, th_pre0 = host.softplus_inverse_inits(np.asarray(self.sigma_sqs_init, dtype=np.float64),

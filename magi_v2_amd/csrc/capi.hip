@@ -114,6 +114,7 @@ void magi_options_from_env(MagiOptions& o) {
     o.sep_pair_min = (int)num("MAGI_SEP_PAIR_MIN", o.sep_pair_min);
     o.fused_parity = num("MAGI_FUSED_PARITY", 0) == 1;
     o.gemm_remap_min = (int)num("MAGI_GEMM_REMAP_MIN", o.gemm_remap_min);
+    o.family_chains = (int)num("MAGI_FAMILY_CHAINS", o.family_chains);
     o.potrf_panels = (int)num("MAGI_POTRF_PANELS", o.potrf_panels);
     o.potrf_lookahead_min = (int)num("MAGI_POTRF_LOOKAHEAD_MIN", o.potrf_lookahead_min);
     o.no_graph = getenv("MAGI_NO_GRAPH") != nullptr;
@@ -890,6 +891,7 @@ int magi_set_option(magi_handle* h, const char* name, int64_t value) {
     MagiOptions& o = h->opt;
     if (k == "stream_family") { if (value < 0 || value > 2) return magi_fail(h, MAGI_E_BADARG, "stream_family: 0 auto, 1 mc, 2 valu"); o.stream_family = (int)value; }
     else if (k == "sep_pair_min") o.sep_pair_min = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
+    else if (k == "family_chains") { if (value < 0 || value > 4096) return magi_fail(h, MAGI_E_BADARG, "family_chains in [0, 4096]"); o.family_chains = (int)value; }
     else if (k == "fused_parity") o.fused_parity = value == 1;
     else if (k == "gemm_remap_min") o.gemm_remap_min = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
     else if (k == "potrf_lookahead_min") { if (value < 0) return magi_fail(h, MAGI_E_BADARG, "potrf_lookahead_min >= 0"); o.potrf_lookahead_min = (int)value; }

@@ -1127,7 +1127,8 @@ int launch_stream_mc(magi_handle* h, int n_chains, int parity, bool with_decisio
 bool magi_stream_family_mc(const magi_handle* h, int n_chains) {
     if (h->opt.stream_family == 1) return true;
     if (h->opt.stream_family == 2) return false;
-    return n_chains >= 3 && (long)h->pb.n_tasks * ((n_chains + 1) / 2) > 320;
+    const int n = h->opt.family_chains > 0 ? std::max(n_chains, h->opt.family_chains) : n_chains;
+    return n >= 3 && (long)h->pb.n_tasks * ((n + 1) / 2) > 320;
 }
 
 bool magi_drift_separable(int drift) {

@@ -845,6 +845,8 @@ __device__ inline FinalizeOut finalize_gradient(const DevProblem& pb, double* vb
 // launch, and a stray variable cannot change what a running job computes between two calls).
 struct MagiOptions {
     int stream_family = 0;              // 0 auto (leap.hip: magi_stream_family_mc), 1 "mc": every batch on the matrix-core kernel, 2 "valu"
+    int family_chains = 0;              // > 0: "auto" decides as if the batch had this many chains (the largest per-GPU share of a sharded job:
+                                        // every rank then runs the same kernel family, whatever its own share -- shard.family_chains_for)
     int sep_pair_min = 256;             // pack.hip: pair the diagonal blocks FH_bb + FK_bb when there are more tasks than this
     int fused_parity = 0;               // magi_logpost_grad_fused evaluates as an even (0) / odd (1) leapfrog slot
     int gemm_remap_min = 24;            // build.hip: super-block tile order from this many super-blocks per launch

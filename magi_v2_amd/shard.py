@@ -20,6 +20,14 @@ def chain_ids_for_rank(rank: int, world: int, chains_total: int) -> List[int]:
     return list(range(start, start + base + (1 if rank < extra else 0)))
 
 
+def family_chains_for(chains_total: int, world: int) -> int:
+    """The largest per-rank share of ``chains_total`` chains over ``world`` ranks.  Every rank passes it to its handle
+    (``set_option("family_chains", ...)`` / ``predict(family_chains=...)``): the streaming-kernel family is then chosen for that count on
+    all ranks, so an uneven shard (20 chains over 8 GPUs: 3, 3, 3, 3, 2, 2, 2, 2) does not put some chains on the matrix-core kernel and
+    others on the VALU kernel -- a chain's samples are bit-identical wherever it runs (the families agree to rounding only)."""
+    return -(-int(chains_total) // max(1, int(world)))
+
+
 def shard_units(n_datasets: int, chains_per_dataset: int, rank: int, world: int) -> List[Tuple[int, List[int]]]:
     """BASELINE config 4 (alpha sweep: 10 datasets x 8 chains): whole datasets are dealt
     round-robin to ranks so that the chains of one dataset share a GPU and its matrices.

@@ -356,7 +356,8 @@ def test_config3_at_size_n1024_eight_chains_per_gpu():
     ids 8r .. 8r+7; here rank 1's block, i.e. ids that are not 0..7).
       * the batch of 8 equals the same ids run as batches of 4, 4 and 3 bit for bit, and -- for two of them -- one at a time
         (the one-chain kernel sums in another order: same tree sizes, states to 1e-8): a chain's samples do not depend on
-        what shares the GPU with it (placement independence, SURVEY 8e);
+        what shares the GPU with it (placement independence); with the option "family_chains" set to the job's largest per-GPU
+        share the one- and two-chain batches are bit-identical too (one kernel family on every rank of an uneven shard);
       * chain 8 equals the CPU oracle draw for draw (tree depths, leapfrog counts, flags exact; states to 1e-8) on the
         GPU-BUILT matrices pulled to the host -- the oracle comparison the small-N sampler tests make, at config 2/3's size."""
     from magi_v2_amd.engine import MagiEngine
@@ -403,6 +404,21 @@ def test_config3_at_size_n1024_eight_chains_per_gpu():
         else:                       # one or two chains run the one-chain kernels: another summation order, same chain to rounding
             np.testing.assert_allclose(Xp, X8[sel], rtol=0, atol=1e-8 * np.abs(X8).max())
             np.testing.assert_allclose(tp_, t8[sel], rtol=1e-7, atol=1e-9)
+    # An uneven shard (say 20 chains over 8 GPUs: 3, 3, 3, 3, 2, 2, 2, 2) would put some chains on the matrix-core kernel and others on the
+    # VALU kernel.  With the job's largest per-GPU share handed to every handle (shard.family_chains_for -> option "family_chains") ONE family
+    # serves every batch: one chain and two chains now equal their rows of the batch of 8 bit for bit as well.
+    from magi_v2_amd.shard import family_chains_for
+    assert family_chains_for(64, 8) == 8 and family_chains_for(20, 8) == 3 and family_chains_for(3, 8) == 1
+    eng.set_option("family_chains", family_chains_for(20, 8))
+    assert eng.stream_kernel_name(2).startswith("k_stream_sep")
+    for part in ([ids[2]], ids[6:8]):
+        (Xp, sp_, tp_), dp, _ = run(part)
+        sel = [ids.index(c) for c in part]
+        np.testing.assert_array_equal(Xp, X8[sel])
+        np.testing.assert_array_equal(tp_, t8[sel])
+        np.testing.assert_array_equal(dp.leapfrogs_taken, d8.leapfrogs_taken[sel])
+    eng.set_option("family_chains", 0)
+    assert eng.stream_kernel_name(2).startswith("k_stream<2>")
     eng.close()
 
     pr = orc.Problem(I=I, mu=Xi.mean(axis=0), C_inv=C_inv, m=m, K_inv=K_inv, N_ds=N_ds.astype(np.float64), obs_idx=idx, y=y,

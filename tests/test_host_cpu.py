@@ -131,3 +131,11 @@ def test_chain_sharding_partitions():
     assert sorted(ds for u in units for ds, _ in u) == list(range(10))
     assert all(ids == [ds * 8 + c for c in range(8)] for u in units for ds, ids in u)
     assert [len(u) for u in units] == [2, 2, 1, 1, 1, 1, 1, 1]
+
+
+def test_family_chains_is_the_largest_per_rank_share():
+    """shard.family_chains_for: what every rank of a sharded job hands to its handle (option "family_chains") so that one streaming-kernel
+    family serves all ranks -- the largest share of chain_ids_for_rank's block partition."""
+    from magi_v2_amd.shard import chain_ids_for_rank, family_chains_for
+    for total, world in ((64, 8), (20, 8), (3, 8), (8, 1), (17, 4), (1, 1)):
+        assert family_chains_for(total, world) == max(len(chain_ids_for_rank(r, world, total)) for r in range(world))
