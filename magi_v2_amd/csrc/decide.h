@@ -46,13 +46,15 @@ __device__ __forceinline__ TailVecs tail_vecs(const DevProblem& pb, double* vb) 
 // The state-sized loop left here: the checkpoint tests of levels >= 5 (one leaf in 32), one workgroup over `dim` entries.
 
 // DualAveragingStepSizeAdaptation.one_step after the inner NUTS step (oracle: dual_averaging_update).
-// Evaluated by one thread; results returned through out[0..3].
+// Evaluated by one thread; results returned through out[0..3].  A function of its own (its five transcendentals stay out of the kernels'
+// bodies) and a LEAF (log / exp / pow are spelled directly here, not as the shared noinline m_log / m_exp: they expand inside it) -- with calls of its own it kept a value in a callee-saved VGPR, whose
+// spill slot was the last scratch reservation of the stream kernels (16 B per lane).
 __device__ __noinline__ void dual_averaging_eval(double target_accept, int n_adapt, int prev, double da_step_size, double da_error_sum,
                                                 double da_log_avg, double da_log_shrink, double e_sum, int lf_count, double* out) {
-    const double log_accept_ratio = m_log(e_sum / (double)lf_count);
+    const double log_accept_ratio = log(e_sum / (double)lf_count);
     double lap = isfinite(log_accept_ratio) ? log_accept_ratio : -INFINITY;
     lap = fmin(lap, 0.0);
-    const double accept = (lap > -INFINITY) ? m_exp(lap) : 0.0;
+    const double accept = (lap > -INFINITY) ? exp(lap) : 0.0;
     const double t = (double)(prev + 1);
     double new_err = da_error_sum + target_accept - accept;
     const double soft_t = 10.0 + t;                              // step_count_smoothing
@@ -60,9 +62,9 @@ __device__ __noinline__ void dual_averaging_eval(double target_accept, int n_ada
     const double eta = pow(t, -0.75);                            // decay_rate
     double new_log_avg = eta * new_log_step + (1.0 - eta) * da_log_avg;
     double new_ss;
-    if (prev < n_adapt) new_ss = m_exp(new_log_step);
+    if (prev < n_adapt) new_ss = exp(new_log_step);
     else if (prev > n_adapt) new_ss = da_step_size;
-    else new_ss = m_exp(new_log_avg);
+    else new_ss = exp(new_log_avg);
     if (prev > n_adapt) { new_err = da_error_sum; new_log_avg = da_log_avg; }
     out[0] = log_accept_ratio;
     out[1] = new_ss;
@@ -93,6 +95,16 @@ __device__ __forceinline__ LeafPlan make_leaf_plan(const ChainCtl& c, unsigned l
     p.chain_id = (unsigned)c.chain_id;
     p.seed = seed;
     return p;
+}
+
+// Field by field: `*out = p` is an aggregate copy, which keeps the fields a caller never touched (the zero tail of a `LeafPlan p{}`) in
+// memory -- 32 bytes of scratch per lane in every stream kernel, two stores and two loads on the decision path (round 3's resource table).
+__device__ __forceinline__ void plan_store(LeafPlan* o, const LeafPlan& p) {
+    static_assert(sizeof(LeafPlan) == 120, "plan_store copies every field: extend it with the struct");
+    o->active = p.active; o->skip = p.skip; o->leaf = p.leaf; o->cur = p.cur; o->even = p.even; o->ck_slot = p.ck_slot; o->nchk = p.nchk;
+    o->chk_slot[0] = p.chk_slot[0]; o->chk_slot[1] = p.chk_slot[1]; o->chk_slot[2] = p.chk_slot[2]; o->chk_slot[3] = p.chk_slot[3];
+    o->leaf_ctr = p.leaf_ctr; o->depth = p.depth; o->step_k = p.step_k; o->chain_id = p.chain_id; o->hs = p.hs; o->eps = p.eps; o->seed = p.seed;
+    o->vop = p.vop; o->vleaf = p.vleaf; o->vdir = p.vdir; o->ndir = p.ndir; o->vout = p.vout; o->sub_copy = p.sub_copy;
 }
 
 // All threads of a 256-thread workgroup call it; `parity` = slot whose stream is running next to these decisions
@@ -184,14 +196,14 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
             c.init_energy = c.cand_bfac * c.cand_L - 0.5 * pp0;
             c.cand_energy = c.init_energy;
             c.phase = PH_LEAF;
-            if (tid == 0) { *plan_out = make_leaf_plan(c, cfg.seed, hmc); ch.ctl[chain] = c; }
+            if (tid == 0) { plan_store(plan_out, make_leaf_plan(c, cfg.seed, hmc)); ch.ctl[chain] = c; }
             return;
         }
         // PH_MERGED: the subtree is merged; does the trajectory go on?
         continue_tree = (dot0 > 0.0) && (dot1 > 0.0);          // (c.cont != 0 and not HMC, or this phase would not have been entered)
         if (continue_tree && c.depth < cfg.max_depth) {
             c.phase = PH_LEAF;                                   // the doubling set up speculatively with the merge stands
-            if (tid == 0) { *plan_out = make_leaf_plan(c, cfg.seed, hmc); ch.ctl[chain] = c; }
+            if (tid == 0) { plan_store(plan_out, make_leaf_plan(c, cfg.seed, hmc)); ch.ctl[chain] = c; }
             return;
         }
         finish = true;                                           // (the proposal was merged with the subtree: nothing of VOP_CAND left)
@@ -199,7 +211,7 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
         if (c.k < stop_k) {
             start = true;                            // resumed by a later magi_sampler_run
         } else {
-            if (tid == 0) { LeafPlan off{}; *plan_out = off; }       // (both ring entries must read "idle")
+            if (tid == 0) { LeafPlan off{}; plan_store(plan_out, off); }       // (both ring entries must read "idle")
             if (c.done_epoch != epoch) {
                 c.done_epoch = epoch;
                 if (tid == 0) {
@@ -216,7 +228,7 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
             LeafPlan p{};
             if (c.phase == PH_LEAF) p = make_leaf_plan(c, cfg.seed, hmc);
             else if (c.phase == PH_INIT) { p.active = 1; p.cur = c.cur; }       // bootstrap gradient, no leapfrog
-            *plan_out = p;
+            plan_store(plan_out, p);
         }
         return;
     } else {
@@ -315,7 +327,7 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
                 if (tid == 0) {
                     LeafPlan pn = make_leaf_plan(c, cfg.seed, hmc);
                     pn.sub_copy = accept_leaf ? 1 : 0;
-                    *plan_out = pn;
+                    plan_store(plan_out, pn);
                     ch.ctl[chain] = c;
                 }
                 MAGI_STAMP(par, 6);
@@ -436,7 +448,7 @@ __device__ __forceinline__ void decide_block(const DevProblem& pb, const DevChai
         p.eps = d_eps; p.hs = d_hs;
         p.vleaf = vleaf; p.vdir = vdir; p.ndir = c.dir; p.vout = vout;
         p.step_k = (unsigned)c.k; p.chain_id = (unsigned)c.chain_id; p.seed = cfg.seed;
-        *plan_out = p;
+        plan_store(plan_out, p);
         ch.ctl[chain] = c;
     }
 }

@@ -7,7 +7,7 @@ r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=
                     "-c", os.path.join(ROOT, "magi_v2_amd/csrc/leap.hip"), "-o", "/tmp/leap_ru.o", "--save-temps"], capture_output=True, text=True)
 txt = r.stderr
 blocks = re.split(r"remark: [^\n]*Function Name: ", txt)[1:]
-print("# hipcc -O3 --offload-arch=gfx950 -ffp-contract=on -Rpass-analysis=kernel-resource-usage magi_v2_amd/csrc/leap.hip  (round 3, ROCm 7.2)")
+print("# hipcc -O3 --offload-arch=gfx950 -ffp-contract=on -Rpass-analysis=kernel-resource-usage magi_v2_amd/csrc/leap.hip  (ROCm 7.2)")
 print("# kernel | VGPRs | VGPR spills | SGPR spills | scratch B/lane | occupancy waves/SIMD | LDS B/block")
 KEYS = ["    VGPRs", "VGPRs Spill", "SGPRs Spill", r"ScratchSize \[bytes/lane\]", r"Occupancy \[waves/SIMD\]", r"LDS Size \[bytes/block\]"]
 for b in blocks:
@@ -23,11 +23,10 @@ s = open("/tmp/leap-hip-amdgcn-amd-amdhsa-gfx950.s").read()
 def body(sym):
     i = s.index("\n" + sym + ":"); j = s.index(".Lfunc_end", i); return s[i:j].split("\n")
 print()
-print("# Scratch (ISA of the same compile; line numbers inside each kernel's body).  Since the state-sized boundary passes moved from the decision workgroup to the")
-print("# point kernel (leap_point.h: boundary_block) the stream kernels spill NO vector register; what is left of the scratch reservation (64 B per lane) are a few")
-print("# accesses on the decision path (decide_block, inlined: it rides in the same kernel, DESIGN.md 4.2).  The streaming workgroups' code -- from the first to the last")
-print("# burst of tile loads -- has no scratch access.  (Before that move: 56-116 spilled VGPRs per kernel, all on the decision path; as a function of its own the")
-print("# decision path ran 40 us and the slot 45 instead of 27-32, so it stayed inlined.)")
+print("# Scratch (ISA of the same compile; line numbers inside each kernel's body).  Round 3: the state-sized boundary passes moved from the decision workgroup to the")
+print("# point kernel (leap_point.h: boundary_block) and the stream kernels stopped spilling vector registers (56-116 per kernel before, all on the decision path).")
+print("# Round 4: the last 64 B per lane of scratch are gone too -- 32 B were the zero tail of a `LeafPlan p{}` kept in memory by the aggregate copy `*plan_out = p`")
+print("# (decide.h: plan_store writes field by field), 16 B the spill slot of a callee-saved VGPR in dual_averaging_eval (now a leaf: its log / exp / pow expand inside it).")
 for sym, what in (("_ZN12_GLOBAL__N_112k_stream_sepILi1ELi8EEEv10DevProblem9DevChains13SamplerCfgDevi", "k_stream_sep<SEIR4, 8>"),
                   ("_ZN12_GLOBAL__N_18k_streamILi1ELi1EEEv10DevProblem9DevChains13SamplerCfgDevi", "k_stream<1, SEIR4>")):
     L = body(sym)
