@@ -436,7 +436,24 @@ __device__ __forceinline__ void dg_tile_gemm(int K, FA a, FB b, double (&c)[2][2
 template <class FA, class FB>
 __device__ __forceinline__ void dg_mfma(int K, FA a, FB b, d4& acc) {
     const int lane = threadIdx.x & 63, li = lane & 15, lj = lane >> 4;
-    for (int k = 0; k < K; k += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a(li, k + lj), b(k + lj, li), acc, 0, 0, 0);
+    // (one k step at a time the loop is a chain of LDS latencies -- operand reads, then the dependent MFMA: ~200 cycles per step, 1.6 k per
+    //  rank-32 tile; with the operands of 8 / 4 steps read ahead the MFMAs issue back to back.  Same accumulation order.)
+    int k = 0;
+    for (; k + 32 <= K; k += 32) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { av[s] = a(li, k + 4 * s + lj); bv[s] = b(k + 4 * s + lj, li); }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+    }
+    for (; k + 16 <= K; k += 16) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { av[s] = a(li, k + 4 * s + lj); bv[s] = b(k + 4 * s + lj, li); }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+    }
+    for (; k < K; k += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a(li, k + lj), b(k + lj, li), acc, 0, 0, 0);
 }
 
 // One wave: Cholesky factor of the 16 x 16 block of S at (b0, b0) and the inverse of that factor, in registers: lane r (& 15) holds
@@ -497,6 +514,17 @@ __device__ __forceinline__ int dg_factor16(double* S, int b0, double* X, int x0)
 #define DG_STAMP_PRINT() do {} while (0)
 #endif
 // grid.x = components of a batch: matrix, inverse block and status word of component z at z * bsA / bsL / bsS
+//
+// Schedule (round 4).  The register factorisation of a 32 x 32 diagonal sub-block (step 1) is a dependent chain on ONE wave -- 25 k of
+// the kernel's 183 k cycles per sub-block, 56 % of the kernel -- and everything else used to wait for it at a barrier.  Now wave 0 is the
+// FACTOR wave and waves 1..3 are WORKERS that do, beside step 1 of sub-block kb, whatever no longer depends on it:
+//     wave 0 :  [update of the next diagonal sub-block (3 tiles of step 3)]  step 1 (kb)
+//     workers:  the other tiles of step 3 (kb - 1)  |  the off-diagonal blocks of the inverse's block row kb - 1  |  stores: block column
+//               kb - 1 of L, finished block rows of the inverse  (iteration 0: the load of everything but the first sub-block)
+// with ONE barrier behind them, then step 2 (rows below the sub-block, all waves) and its barrier.  A job of the inverse is a 32 x 16 half
+// of a block on one wave, its intermediate product kept in the accumulators (the C layout of v_mfma_f64_16x16x4_f64 -- lane holds rows
+// (lane >> 4) + 4 r of column lane & 15 -- is the B-operand layout of the following product), so workers never synchronise with each other.
+// Every element takes the same operations in the same order as before: the outputs are bit-identical to the round-3 kernel's.
 __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int n, double* Linv /* [128][128] */, int* status, int block_row0,
                                                        long bsA, long bsL, int bsS) {
     A += (long)blockIdx.x * bsA; Linv += (long)blockIdx.x * bsL; status += (long)blockIdx.x * bsS;
@@ -507,159 +535,192 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
     double* S = lds;                               // [128][DG_LD]
     double* dinv = lds + 128 * DG_LD;              // diagonal of the inverse
     double* T = dinv + 128;                        // [32][33]
-    double* T1 = T + 32 * 33;                      // dense copies of two diagonal blocks of the inverse
+    double* T1 = T + 32 * 33;                      // dense inverse of the diagonal sub-block in flight (step 1 -> step 2)
     double* T2 = T1 + 32 * 33;
     int& bad = *reinterpret_cast<int*>(T2 + 32 * 33);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lj = lane >> 4;
     if (tid == 0) bad = -1;
     DG_STAMP(0);
-    // (32 loads in flight per thread -- two batches for the block -- and only the lower triangle is fetched: `S[..] = cond ? A[..] : pad`
-    //  in a plain loop is a load -> LDS store chain, one memory round trip per element; 8 per batch measured 17 k cycles of 290 k)
-    for (int e0 = tid; e0 < 128 * 128; e0 += 256 * 32) {
-        double v[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const int e = e0 + 256 * u, i = e >> 7, j = e & 127;
-            v[u] = (j <= i && i < n) ? A[(long)i * lda + j] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const int e = e0 + 256 * u, i = e >> 7, j = e & 127;
-            S[i * DG_LD + j] = (i < n && j < n) ? v[u] : ((i == j) ? 1.0 : 0.0);      // identity padding; zeros above the diagonal
-        }
-    }
-    __syncthreads();
-    DG_STAMP(1);
     const int nsb = (n + 31) >> 5, nl = 32 * nsb;          // live 32-wide sub-blocks (the identity padding behind them factors to itself)
 
+    // ---- pieces --------------------------------------------------------------------------------------------------------------------
+    // elements e = i * 128 + j of the block, e in {t, t + nt, ...}, rows [r0, r1): global -> S (lower triangle; identity padding; zeros above),
+    // 16 loads in flight per thread (`S[..] = cond ? A[..] : pad` in a plain loop is a load -> LDS store chain, one round trip per element)
+    // (lw = log2 of the region's width: 5 or 7)
+    auto load_rows = [&](int r0, int r1, int lw, int t, int nt) {
+        const int cnt = (r1 - r0) << lw, wm = (1 << lw) - 1;
+        for (int e0 = t; e0 < cnt; e0 += nt * 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = e0 + nt * u, i = r0 + (e >> lw), j = e & wm;
+                v[u] = (e < cnt && j <= i && i < n) ? A[(long)i * lda + j] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = e0 + nt * u, i = r0 + (e >> lw), j = e & wm;
+                if (e < cnt) S[i * DG_LD + j] = (i < n && j < n) ? v[u] : ((i == j) ? 1.0 : 0.0);
+            }
+        }
+    };
+    // step 1 of sub-block kb (one wave): two 16 x 16 register factorisations (dg_factor16) with the rank-16 update and the off-diagonal block of
+    // the inverse between them on the matrix cores (wave-private: LDS operations of a wave are ordered).  T1 <- dense inv(L11) (32 x 32).
+    auto step1 = [&](int c0) {
+        const int c1 = c0 + 16;
+        int fail = dg_factor16(S, c0, T1, 0);
+        {   // L21 = A21 X11a^T ; A22 -= L21 L21^T
+            d4 o = d4{0.0, 0.0, 0.0, 0.0};
+            dg_mfma(16, [&](int m, int k) { return S[(c1 + m) * DG_LD + c0 + k]; }, [&](int k, int nn) { return T1[nn * 33 + k]; }, o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(c1 + lj + 4 * r) * DG_LD + c0 + li] = o[r];
+            d4 u = d4{0.0, 0.0, 0.0, 0.0};
+            dg_mfma(16, [&](int m, int k) { return S[(c1 + m) * DG_LD + c0 + k]; }, [&](int k, int nn) { return S[(c1 + nn) * DG_LD + c0 + k]; }, u);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(c1 + lj + 4 * r) * DG_LD + c1 + li] -= u[r];
+        }
+        const int fail2 = dg_factor16(S, c1, T1, 16);
+        if (fail < 0) fail = fail2;
+        if (fail >= 0 && lane == 0) bad = fail;
+        {   // X21 = -X22 (L21 X11a)
+            d4 tm = d4{0.0, 0.0, 0.0, 0.0};
+            dg_mfma(16, [&](int m, int k) { return S[(c1 + m) * DG_LD + c0 + k]; }, [&](int k, int nn) { return T1[k * 33 + nn]; }, tm);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[(lj + 4 * r) * 33 + li] = tm[r];
+            d4 o = d4{0.0, 0.0, 0.0, 0.0};
+            dg_mfma(16, [&](int m, int k) { return T1[(16 + m) * 33 + 16 + k]; }, [&](int k, int nn) { return T[k * 33 + nn]; }, o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { T1[(16 + lj + 4 * r) * 33 + li] = -o[r]; T1[(lj + 4 * r) * 33 + 16 + li] = 0.0; }
+        }
+    };
+    // all threads, behind the barrier that ends step 1: T1 -> the form the rest of the kernel reads (diagonal -> dinv, strict lower part of the
+    // inverse -> the upper triangle of S, transposed).  (On the factor wave alone: 16 dependent LDS round trips on the critical path.)
+    auto publish = [&](int c0) {
+        for (int e = tid; e < 32 * 32; e += 256) {
+            const int c = e >> 5, k = e & 31;
+            const double v = T1[c * 33 + k];
+            if (k == c) dinv[c0 + c] = v;
+            else if (k < c) S[(c0 + k) * DG_LD + c0 + c] = v;
+        }
+    };
+    // one 16 x 16 tile (I, J) of step 3 after sub-block cp: A22 -= L21 L21^T, rank 32 (a diagonal tile also writes its upper half: those
+    // entries belong to later diagonal sub-blocks' upper triangles, which step 1 masks when it reads and overwrites with the inverse)
+    auto trail_tile = [&](int cp, int I, int J) {
+        const int m0 = cp + 32, i0 = m0 + 16 * I, j0 = m0 + 16 * J;
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+        dg_mfma(32, [&](int m, int k) { return S[(i0 + m) * DG_LD + cp + k]; }, [&](int k, int nn) { return S[(j0 + nn) * DG_LD + cp + k]; }, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(i0 + lj + 4 * r) * DG_LD + j0 + li] -= acc[r];
+    };
+    // the inverse's diagonal blocks live as a transposed triangle + a separate diagonal
+    auto Xf = [&](int i, int j) -> double { return i == j ? dinv[i] : (i > j ? S[j * DG_LD + i] : 0.0); };
+    // one wave: columns [16 h, 16 h + 16) of X_{bi,bj} = -X_ii * sum_{k = bj}^{bi - 1} L_ik X_kj   (block rows in order: X_kj, k < bi, are complete)
+    auto xjob = [&](int bi, int bj, int h) {
+        const int tj = 16 * h, ri = 32 * bi, rj = 32 * bj;
+        d4 w[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ti = 16 * q;
+            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+            dg_mfma(32, [&](int m, int k) { return S[(ri + ti + m) * DG_LD + rj + k]; }, [&](int k, int nn) { return Xf(rj + k, rj + tj + nn); }, acc);
+            dg_mfma((bi - bj - 1) * 32, [&](int m, int k) { return S[(ri + ti + m) * DG_LD + rj + 32 + k]; },
+                    [&](int k, int nn) { return S[(rj + tj + nn) * DG_LD + rj + 32 + k]; }, acc);
+            w[q] = acc;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ti = 16 * q;
+            d4 out = d4{0.0, 0.0, 0.0, 0.0};
+            double xa[8];
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) xa[s8] = Xf(ri + ti + li, ri + 4 * s8 + lj);
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8)        // B operand of step k = 4 s8: W[k + lj][li] = the accumulator entry that holds row lj + 4 (s8 & 3) of half s8 >> 2
+                out = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[s8], w[s8 >> 2][s8 & 3], out, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(rj + tj + li) * DG_LD + ri + ti + lj + 4 * r] = -out[r];      // X_ij[ti + row][tj + col], stored transposed
+        }
+    };
+    // block column cb of L (and the zeros above the diagonal) -> global; block row rb of the dense inverse -> global
+    auto store_L_cols = [&](int cb, int t, int nt) {
+#pragma unroll 8
+        for (int e = t; e < 128 * 32; e += nt) {
+            const int i = e >> 5, j = 32 * cb + (e & 31);
+            const double v = S[i * DG_LD + j];
+            if (i < n && j < n) A[(long)i * lda + j] = (j <= i) ? v : 0.0;
+        }
+    };
+    auto store_Linv_rows = [&](int rb, int t, int nt) {
+#pragma unroll 8
+        for (int e = t; e < 32 * 128; e += nt) {
+            const int i = 32 * rb + (e >> 7), j = e & 127;
+            const double v = S[min(j, i) * DG_LD + max(j, i)], dv = dinv[i];
+            Linv[i * 128 + j] = (i < n && j <= i) ? (i == j ? dv : v) : 0.0;
+        }
+    };
+
+    // ---- the schedule ---------------------------------------------------------------------------------------------------------------
+    const int wt = tid - 64;                        // worker thread index (192 of them)
     for (int kb = 0; kb < nsb; ++kb) {
         const int c0 = 32 * kb;
-        // ---- 1. diagonal 32 x 32 sub-block by wave 0: two 16 x 16 register factorisations (dg_factor16) with the rank-16 update and the
-        //         off-diagonal block of the inverse between them on the matrix cores (wave-private: LDS operations of a wave are ordered).
-        //         T1 <- dense inv(L11) (32 x 32), then published as the transposed triangle + diagonal the rest of the kernel reads. ----
         if (wave == 0) {
-            const int li = lane & 15, lj = lane >> 4, c1 = c0 + 16;
-            int fail = dg_factor16(S, c0, T1, 0);
-            {   // L21 = A21 X11a^T ; A22 -= L21 L21^T
-                d4 o = d4{0.0, 0.0, 0.0, 0.0};
-                dg_mfma(16, [&](int m, int k) { return S[(c1 + m) * DG_LD + c0 + k]; }, [&](int k, int n) { return T1[n * 33 + k]; }, o);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[(c1 + lj + 4 * r) * DG_LD + c0 + li] = o[r];
-                d4 u = d4{0.0, 0.0, 0.0, 0.0};
-                dg_mfma(16, [&](int m, int k) { return S[(c1 + m) * DG_LD + c0 + k]; }, [&](int k, int n) { return S[(c1 + n) * DG_LD + c0 + k]; }, u);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[(c1 + lj + 4 * r) * DG_LD + c1 + li] -= u[r];
-            }
-            const int fail2 = dg_factor16(S, c1, T1, 16);
-            if (fail < 0) fail = fail2;
-            if (fail >= 0 && lane == 0) bad = fail;
-            {   // X21 = -X22 (L21 X11a)
-                d4 tm = d4{0.0, 0.0, 0.0, 0.0};
-                dg_mfma(16, [&](int m, int k) { return S[(c1 + m) * DG_LD + c0 + k]; }, [&](int k, int n) { return T1[k * 33 + n]; }, tm);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) T[(lj + 4 * r) * 33 + li] = tm[r];
-                d4 o = d4{0.0, 0.0, 0.0, 0.0};
-                dg_mfma(16, [&](int m, int k) { return T1[(16 + m) * 33 + 16 + k]; }, [&](int k, int n) { return T[k * 33 + n]; }, o);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { T1[(16 + lj + 4 * r) * 33 + li] = -o[r]; T1[(lj + 4 * r) * 33 + 16 + li] = 0.0; }
-            }
-            // publish: diagonal -> dinv, strict lower part of the inverse -> the upper triangle of S, transposed
-            for (int e = lane; e < 32 * 32; e += 64) {
-                const int c = e >> 5, k = e & 31;
-                const double v = T1[c * 33 + k];
-                if (k == c) dinv[c0 + c] = v;
-                else if (k < c) S[(c0 + k) * DG_LD + c0 + c] = v;
+            if (kb == 0) load_rows(0, 32, 5, lane, 64);                            // the first sub-block (the rest arrives beside its factorisation)
+            else { trail_tile(c0 - 32, 0, 0); trail_tile(c0 - 32, 1, 0); trail_tile(c0 - 32, 1, 1); }
+            step1(c0);
+        } else {
+            if (kb == 0) {
+                for (int e = wt; e < 32 * 96; e += 192) S[(e / 96) * DG_LD + 32 + e % 96] = 0.0;      // rows of the first sub-block right of it: above the diagonal
+                load_rows(32, 128, 7, wt, 192);
+            } else {
+                const int mt = (nl - c0) >> 4;                                       // 16-tiles per side of the trailing matrix behind sub-block kb - 1
+                for (int t = 3 + (wave - 1); t < mt * (mt + 1) / 2; t += 3) {        // t = I (I + 1) / 2 + J; tiles 0, 1, 2 (the next sub-block) are wave 0's
+                    int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                    while (I * (I + 1) / 2 > t) --I;
+                    while ((I + 1) * (I + 2) / 2 <= t) ++I;
+                    trail_tile(c0 - 32, I, t - I * (I + 1) / 2);
+                }
+                // block row kb - 1 of the inverse (its diagonal block was published before the last barrier): 2 (kb - 1) jobs
+                for (int job = wave - 1; job < 2 * (kb - 1); job += 3) xjob(kb - 1, job >> 1, job & 1);
+                store_L_cols(kb - 1, wt, 192);
+                if (kb == 1) store_Linv_rows(0, wt, 192);                            // (block row 0 is its diagonal block)
+                else if (kb >= 3) store_Linv_rows(kb - 2, wt, 192);                  // (block row kb - 2 was completed beside step 1 of kb - 1)
             }
         }
         __syncthreads();
         DG_STAMP(2 + 3 * kb);
         if (bad >= 0) break;
+        publish(c0);
         if (kb == nsb - 1) break;
         // ---- 2. rows below: L21 = A21 * inv(L11)^T on the matrix cores: 16-row tiles over the waves, both 16-column halves per tile ----
-        {   // (T1 holds the dense inv(L11) from step 1)
-            const int li = lane & 15, lj = lane >> 4;
-            for (int rt = wave; 16 * rt < nl - c0 - 32; rt += 4) {
-                const int i0 = c0 + 32 + 16 * rt;
-                d4 o0 = d4{0.0, 0.0, 0.0, 0.0}, o1 = d4{0.0, 0.0, 0.0, 0.0};
-                dg_mfma(32, [&](int m, int k) { return S[(i0 + m) * DG_LD + c0 + k]; }, [&](int k, int n) { return T1[n * 33 + k]; }, o0);
-                dg_mfma(32, [&](int m, int k) { return S[(i0 + m) * DG_LD + c0 + k]; }, [&](int k, int n) { return T1[(16 + n) * 33 + k]; }, o1);
-                // (the tile's rows are read by this wave only, and all its reads precede these writes: the MFMA results depend on them)
+        for (int rt = wave; 16 * rt < nl - c0 - 32; rt += 4) {
+            const int i0 = c0 + 32 + 16 * rt;
+            d4 o0 = d4{0.0, 0.0, 0.0, 0.0}, o1 = d4{0.0, 0.0, 0.0, 0.0};
+            dg_mfma(32, [&](int m, int k) { return S[(i0 + m) * DG_LD + c0 + k]; }, [&](int k, int nn) { return T1[nn * 33 + k]; }, o0);
+            dg_mfma(32, [&](int m, int k) { return S[(i0 + m) * DG_LD + c0 + k]; }, [&](int k, int nn) { return T1[(16 + nn) * 33 + k]; }, o1);
+            // (the tile's rows are read by this wave only, and all its reads precede these writes: the MFMA results depend on them)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    S[(i0 + lj + 4 * r) * DG_LD + c0 + li] = o0[r];
-                    S[(i0 + lj + 4 * r) * DG_LD + c0 + 16 + li] = o1[r];
-                }
+            for (int r = 0; r < 4; ++r) {
+                S[(i0 + lj + 4 * r) * DG_LD + c0 + li] = o0[r];
+                S[(i0 + lj + 4 * r) * DG_LD + c0 + 16 + li] = o1[r];
             }
         }
         __syncthreads();
         DG_STAMP(3 + 3 * kb);
-        // ---- 3. trailing update A22 -= L21 L21^T on the lower 16 x 16 tiles (rank 32: 8 MFMAs per tile) ----
-        //         (a diagonal tile also writes its upper half: those entries belong to later diagonal sub-blocks' upper triangles,
-        //          which step 1 masks when it reads and overwrites with the inverse)
-        {
-            const int li = lane & 15, lj = lane >> 4;
-            const int m0 = c0 + 32, mt = (nl - m0) >> 4;           // 16-tiles per side
-            for (int t = wave; t < mt * (mt + 1) / 2; t += 4) {    // t = I (I + 1) / 2 + J
-                int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-                while (I * (I + 1) / 2 > t) --I;
-                while ((I + 1) * (I + 2) / 2 <= t) ++I;
-                const int J = t - I * (I + 1) / 2;
-                const int i0 = m0 + 16 * I, j0 = m0 + 16 * J;
-                d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-                dg_mfma(32, [&](int m, int k) { return S[(i0 + m) * DG_LD + c0 + k]; }, [&](int k, int n) { return S[(j0 + n) * DG_LD + c0 + k]; }, acc);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[(i0 + lj + 4 * r) * DG_LD + j0 + li] -= acc[r];
-            }
-        }
-        __syncthreads();
-        DG_STAMP(4 + 3 * kb);
     }
     if (bad >= 0) {
         if (tid == 0) atomicCAS(status, -1, block_row0 + bad);
         return;
     }
-    // ---- off-diagonal blocks of the inverse: X_ij = -X_ii * sum_{k=j}^{i-1} L_ik X_kj  (block rows in order) -----------------------
-    auto Xf = [&](int i, int j) -> double { return i == j ? dinv[i] : (i > j ? S[j * DG_LD + i] : 0.0); };
-    for (int bi = 1; bi < nsb; ++bi)
-        for (int bj = 0; bj < bi; ++bj) {
-            // the diagonal blocks X_jj, X_ii live as a transposed triangle + a separate diagonal (Xf): dense copies for the MFMA operands
-            for (int e = tid; e < 32 * 32; e += 256) {
-                const int i = e >> 5, j = e & 31;
-                T1[i * 33 + j] = Xf(32 * bj + i, 32 * bj + j);
-                T2[i * 33 + j] = Xf(32 * bi + i, 32 * bi + j);
-            }
-            __syncthreads();
-            // wave = 16 x 16 quarter (ti, tj) of the 32 x 32 block
-            const int li = lane & 15, lj = lane >> 4, ti = 16 * (wave >> 1), tj = 16 * (wave & 1);
-            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-            dg_mfma(32, [&](int m, int k) { return S[(32 * bi + ti + m) * DG_LD + 32 * bj + k]; },
-                    [&](int k, int n) { return T1[k * 33 + tj + n]; }, acc);
-            dg_mfma((bi - bj - 1) * 32, [&](int m, int k) { return S[(32 * bi + ti + m) * DG_LD + 32 * bj + 32 + k]; },
-                    [&](int k, int n) { return S[(32 * bj + tj + n) * DG_LD + 32 * bj + 32 + k]; }, acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) T[(ti + lj + 4 * r) * 33 + tj + li] = acc[r];
-            __syncthreads();
-            d4 out = d4{0.0, 0.0, 0.0, 0.0};
-            dg_mfma(32, [&](int m, int k) { return T2[(ti + m) * 33 + k]; }, [&](int k, int n) { return T[k * 33 + tj + n]; }, out);
-            __syncthreads();                       // every wave is done with T and with the X blocks it read
-#pragma unroll
-            for (int r = 0; r < 4; ++r) S[(32 * bj + tj + li) * DG_LD + 32 * bi + ti + lj + 4 * r] = -out[r];      // X_ij[ti + row][tj + col], stored transposed
-            __syncthreads();
-        }
+    // ---- tail: the last block row of the inverse (2 (nsb - 1) jobs over the four waves), then what is not stored yet ----
+    __syncthreads();                                    // (the last sub-block's inverse is published)
+    for (int job = wave; job < 2 * (nsb - 1); job += 4) xjob(nsb - 1, job >> 1, job & 1);
+    __syncthreads();
     DG_STAMP(14);
-    // L back into the block (lower triangle; zeros above it) and the dense inverse: eight elements' LDS reads in flight per thread
-#pragma unroll 8
-    for (int e = tid; e < 128 * 128; e += 256) {
-        const int i = e >> 7, j = e & 127;
-        const double v = S[i * DG_LD + j];
-        if (i < n && j < n) A[(long)i * lda + j] = (j <= i) ? v : 0.0;
-    }
-#pragma unroll 8
-    for (int e = tid; e < 128 * 128; e += 256) {
-        const int i = e >> 7, j = e & 127;
-        const double v = S[min(j, i) * DG_LD + max(j, i)], dv = dinv[i];
-        Linv[e] = (i < n && j <= i) ? (i == j ? dv : v) : 0.0;
-    }
+    store_L_cols(nsb - 1, tid, 256);
+    if (nsb == 1) store_Linv_rows(0, tid, 256);
+    if (nsb >= 3) store_Linv_rows(nsb - 2, tid, 256);
+    if (nsb >= 2) store_Linv_rows(nsb - 1, tid, 256);
+    for (int rb = nsb; rb < 4; ++rb) store_Linv_rows(rb, tid, 256);           // rows >= n of the dense inverse are zeros
     DG_STAMP(15);
     DG_STAMP_PRINT();
 }
