@@ -88,9 +88,11 @@ def test_build_matrices_vs_reference_golden(eng):
         assert np.abs(R).max() < max(50 * cond * EPS, 2e-7) * np.linalg.cond(g[f"{tag}_K"]), (tag, np.abs(R).max())
 
 
-@pytest.mark.parametrize("N", [161, 300, 513])
+@pytest.mark.parametrize("N", [20, 96, 161, 200, 250, 300, 513])
 def test_build_multi_block_inverse_property(eng, N):
-    """Sizes that are not multiples of the 128-wide Cholesky block; D = 2 components."""
+    """Sizes that are not multiples of the 128-wide Cholesky block; D = 2 components.  The last diagonal block has n = N mod 128 rows and
+    the diagonal-block kernel works on ceil(n / 32) sub-blocks of 32 with an identity padding: 20 and 513 (one sub-block), 161 and 300 (two),
+    96 and 200 (three), 250 (four, ragged) -- every count takes its own path through the kernel's schedule of factor and worker waves."""
     I = np.arange(N) * 0.025
     phi1, phi2 = np.array([0.03, 0.2]), np.array([0.3, 0.15])
     C_inv, m, K_inv = eng.build_matrices(I, phi1, phi2, 2.01)
