@@ -713,7 +713,12 @@ __global__ __launch_bounds__(256) void k_diag_chol_inv(double* A, long lda, int 
     }
     // ---- tail: the last block row of the inverse (2 (nsb - 1) jobs over the four waves), then what is not stored yet ----
     __syncthreads();                                    // (the last sub-block's inverse is published)
-    for (int job = wave; job < 2 * (nsb - 1); job += 4) xjob(nsb - 1, job >> 1, job & 1);
+    // (jobs in the order of their length -- block column 0 takes nsb - 1 products, the last one takes one: the second round goes to the waves
+    //  in reverse, so that the wave with the longest first job gets no second one)
+    for (int round = 0, base = 0; base < 2 * (nsb - 1); ++round, base += 4) {
+        const int job = base + ((round & 1) ? 3 - wave : wave);
+        if (job < 2 * (nsb - 1)) xjob(nsb - 1, job >> 1, job & 1);
+    }
     __syncthreads();
     DG_STAMP(14);
     store_L_cols(nsb - 1, tid, 256);
