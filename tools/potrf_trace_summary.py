@@ -33,7 +33,7 @@ for j0 in range(0, N, NPAN * NB):
         seq.append(("trailing", 2.0 * tiles * 128 * 128 * NPAN * NB * D, tiles * D))
 per_fact = len(seq)
 nfact = len(rk) // per_fact
-print(f"{len(rk)} rank-k launches = {nfact} factorisations x {per_fact} ({nbuild} build(s)); diag {np.sum(diag) / nbuild:.2f} ms, panels {np.sum(pan) / nbuild:.2f} ms per build")
+print(f"{len(rk)} rank-k launches = {nfact} factorisations x {per_fact} ({nbuild} build(s)); diag {np.sum(diag) / nbuild / 1e3:.2f} ms, panels {np.sum(pan) / nbuild / 1e3:.2f} ms per build")
 acc = {"tall": [0.0, 0.0, 0], "trailing": [0.0, 0.0, 0]}
 detail = []
 for i, d_ in enumerate(dur[: nfact * per_fact]):
