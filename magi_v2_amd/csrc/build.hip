@@ -191,6 +191,7 @@ struct GemmArgs {
     double* C2; long ldc2, batchC2t;   // optional second output, TRANSPOSED: C2[n * ldc2 + m] = alpha * sum (the Cholesky panels are kept in
                                    // both orientations: the rank-k updates then read both operands along their unit-stride dimension)
     int remap;                     // set by launch_gemm: XCD-aware super-block tile order (large tile grids)
+    int remap_min;                 // > 0: this launch's own threshold (super-blocks) for that order instead of the option's
     int zinner;                    // > 0: grid.z = zinner x outer; batch* step the inner index, batch*2 the outer one
     long batchA2, batchB2, batchC2;
 };
@@ -349,8 +350,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAGI_GEMM_O
         if (g.kmode == 4) bx = tX - 1 - bx;
     } else {
     const int i = (int)blockIdx.x, j = i >> 3;
-    const int u = (j >> 6) * 8 + (((i & 7) + (j >> 6)) & 7), w = j & 63;      // (rotated: an XCD must not keep ONE super-column -- k ranges
-                                                                               //  that depend on the column would all be long on one XCD)
+    // (rotated by the round AND by the batch index: an XCD must not keep ONE super-column -- k ranges that depend on the column would all be
+    //  long on one XCD.  The round alone is not enough: a 32 x 32-tile launch has 16 super-blocks, two rounds, so an XCD sees two of the four
+    //  super-columns, and with the same two for every component of the batch XCDs 0 and 4 carried 1.5 x the mean of trtri's first product --
+    //  it took as long as over the full K range, 0.46 of the MFMA peak against 0.85 for its twin (profiles/r04_trtri_by_level.txt))
+    const int u = (j >> 6) * 8 + (((i & 7) + (j >> 6) + 3 * (int)blockIdx.z) & 7), w = j & 63;
     int sy, sx;
     if (g.lower_only) {
         sy = (int)((sqrtf(8.0f * (float)u + 1.0f) - 1.0f) * 0.5f);
@@ -958,7 +962,8 @@ int launch_gemm(magi_handle* h, hipStream_t s, const GemmArgs& g_in, int batch =
     const int tY = (g.M + GT - 1) / GT, tX = (g.N + GT - 1) / GT, sY = (tY + 7) / 8, sX = (tX + 7) / 8;
     const int nsuper = g.lower_only ? sY * (sY + 1) / 2 : sY * sX;           // (lower-only: square tile grids)
     // (an option of the handle: tests/test_fullsize_gpu.py forces the super-block order on small tile grids with gemm_remap_min = 1)
-    const int remap_min = h->opt.gemm_remap_min;
+    // (a launch's own threshold holds while the option is at its default; an explicit option value -- the tests force the order with 1 -- rules them all)
+    const int remap_min = (g.remap_min > 0 && h->opt.gemm_remap_min == MAGI_GEMM_REMAP_MIN_DEFAULT) ? g.remap_min : h->opt.gemm_remap_min;
     g.remap = (nsuper >= remap_min && (!g.lower_only || tY == tX)) ? 1 : 0;
     dim3 grid(g.remap ? ((nsuper + 7) / 8) * 8 * 64 : tY * tX, 1, batch);
     prof_begin(s);
@@ -1047,6 +1052,7 @@ int potrf(Linalg& la, double* A, const char* what, bool defer_status = false, in
         g.B = la.dinv + (size_t)(j0 / NB) * 128 * 128; g.sBn = 128; g.sBk = 1;
         g.C = P; g.ldc = N; g.M = N - row0; g.N = n; g.K = n; g.alpha = 1.0; g.beta = 0.0;
         g.batchA = la.bsA; g.batchB = la.bs_dinv; g.batchC = la.bsA;
+        g.remap_min = 24;           // (thin launches: the plain order is the better one until the tile grid is large, profiles/r04_gemm_remap_min_sweep.txt)
         return launch_gemm(h, sc, g, la.batch, BC_PANEL);
     };
     // (a transposed copy of the panels, so that this update reads both operands along their unit-stride dimension, was measured:
@@ -1059,6 +1065,7 @@ int potrf(Linalg& la, double* A, const char* what, bool defer_status = false, in
         t.C = A + (size_t)row0 * N + row0; t.ldc = N; t.M = N - row0; t.N = ncols; t.K = K; t.alpha = -1.0; t.beta = 1.0;
         t.lower_only = ncols > GT ? 1 : 0;          // (a single tile column has no tile above the diagonal)
         t.batchA = la.bsA; t.batchB = la.bsA; t.batchC = la.bsA;
+        t.remap_min = 24;
         return launch_gemm(h, st, t, la.batch, BC_TRAIL);
     };
     // outer block column = NPAN panels of 128 (left-looking inside it: panel c first takes the rank-128c update of the panels
@@ -1145,6 +1152,10 @@ int trtri(Linalg& la, double* A) {
             g.B = base; g.sBn = 1; g.sBk = N;
             g.C = la.panel; g.ldc = s; g.M = M2; g.N = (int)s; g.K = (int)s; g.alpha = 1.0; g.beta = 0.0; g.kmode = 3;
             g.zinner = pairs;
+            // (triangular k ranges: in plain tile order the tiles of a row start their K walks at different places and each streams its own stretch
+            //  of the shared operand panel -- this product ran at 0.46 of the MFMA peak at every level, as long as over the FULL K range, beside
+            //  0.85 for its twin; in super-block order, which the top level of a large grid now gets (gemm_remap_min 24 -> 10), 0.72 for the class:
+            //  profiles/r04_trtri_by_level.txt, r04_gemm_remap_min_sweep.txt)
             g.batchA = pstride; g.batchB = pstride; g.batchC = s * s;
             g.batchA2 = la.bsA; g.batchB2 = la.bsA; g.batchC2 = la.bs_panel;
             int rc = launch_gemm(h, la.s, g, pairs * la.batch, BC_TRTRI);

@@ -843,13 +843,15 @@ __device__ inline FinalizeOut finalize_gradient(const DevProblem& pb, double* vb
 // Tuning / test switches of a handle.  The environment variables of the same names (MAGI_STREAM_FAMILY, ...) are read ONCE, when the
 // handle is created; afterwards only magi_set_option changes them (no getenv on any compute path: a concurrent setenv cannot race a
 // launch, and a stray variable cannot change what a running job computes between two calls).
+#define MAGI_GEMM_REMAP_MIN_DEFAULT 10
 struct MagiOptions {
     int stream_family = 0;              // 0 auto (leap.hip: magi_stream_family_mc), 1 "mc": every batch on the matrix-core kernel, 2 "valu"
     int family_chains = 0;              // > 0: "auto" decides as if the batch had this many chains (the largest per-GPU share of a sharded job:
                                         // every rank then runs the same kernel family, whatever its own share -- shard.family_chains_for)
     int sep_pair_min = 256;             // pack.hip: pair the diagonal blocks FH_bb + FK_bb when there are more tasks than this
     int fused_parity = 0;               // magi_logpost_grad_fused evaluates as an even (0) / odd (1) leapfrog slot
-    int gemm_remap_min = 24;            // build.hip: super-block tile order from this many super-blocks per launch
+    int gemm_remap_min = MAGI_GEMM_REMAP_MIN_DEFAULT;      // build.hip: super-block tile order from this many super-blocks per launch (24 until round 4;
+                                        // while it is at its default, potrf's thin launches keep 24: GemmArgs::remap_min)
     int potrf_panels = 3;               // build.hip: 128-wide panels per block column of the Cholesky factorisation (3: best of 2..8 at N = 1024..8192, profiles/r04_potrf_lookahead_ab.txt)
     int potrf_lookahead_min = 4096;     // build.hip: grids from this size on factorise with look-ahead (0: never), see potrf
     long long slot_budget_graphs = 0;   // TEST HOOK: cap on the graph launches of one magi_sampler_run (0 = the computed bound)

@@ -20,6 +20,9 @@ MAGI_GRAPH_SLOTS=2 timeout -k 10 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_build8k -- python3 tools/exp_build_once.py 8192 3 nola > $O/kt_build8k.log 2>&1 || exit 1
 MAGI_BUILD_PROFILE=1 timeout -k 10 200 python3 tools/exp_build_profile.py 8192 > $O/build_profile_n8192.json 2> $O/build_profile.err || exit 1
 python3 tools/potrf_trace_summary.py $(ls $O/kt_build8k/*/*kernel_trace.csv | head -1) 8192 4 3 > $O/potrf_rank_k_by_launch.txt 2>&1
+python3 tools/trtri_trace_summary.py $(ls $O/kt_build8k/*/*kernel_trace.csv | head -1) 8192 4 > $O/trtri_by_level.txt 2>&1
+timeout -k 10 300 python3 tools/exp_remap_min.py 8192 10 24 > $O/gemm_remap_min_8192.txt 2>&1
+timeout -k 10 300 python3 tools/exp_remap_min.py 4096 10 24 > $O/gemm_remap_min_4096.txt 2>&1
 # the factorisation with look-ahead: A/B on the device clock, and who overlaps whom (kernel trace of a build with look-ahead on)
 timeout -k 10 300 python3 tools/exp_potrf_lookahead.py 8192 3 > $O/potrf_lookahead_ab.txt 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/kt_build8k_la -- python3 tools/exp_build_once.py 8192 2 > $O/kt_build8k_la.log 2>&1 || exit 1
