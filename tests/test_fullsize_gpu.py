@@ -9,7 +9,7 @@ cannot run there in seconds:
   * config 5 (N = 8192): the build's OUTPUTS against Matern columns evaluated by the oracle (never downloads a matrix).
 
 Which test pins which GEMM class of csrc/build.hip (k_gemm_f64<CLS>; the XCD-aware super-block tile order switches on by itself
-only above N = 4096, `MAGI_GEMM_REMAP_MIN=1` forces it on every launch):
+from N = 4096 on, `MAGI_GEMM_REMAP_MIN=1` forces it on every launch):
   <2> potrf panels, <3> potrf rank-k updates, <4> trtri, <5> T^T T, <6> W^T / m / K_d products
       -- plain tile order:  test_full_size_inverse_properties[1024 / 2048] (dense host truth: C^-1 Kappa = I, m Kappa = p_Kappa,
          K^-1 K_ref = I), tests/test_build_gpu.py (mpmath / reference golden at small N);
