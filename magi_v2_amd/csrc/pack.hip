@@ -182,6 +182,20 @@ int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double*
                         if (std::abs(bi - bj) > wb) continue;
                         tasks.push_back(d); tasks.push_back(kind); tasks.push_back(bi); tasks.push_back(bj);
                     }
+        // Launch order = task order, and the hardware fills the CUs two workgroups at a time: with 544 blocks on 256 CUs (N = 1024, dense) the LAST
+        // 32 tasks become the third workgroup of 32 CUs, which then stream 384 KB instead of 256 KB and end last (profiles/r04_wg_trace_1chain.txt).
+        // The diagonal blocks of FH are the lightest tasks (row-type product only, no theta' in front): they go to the end of the list: same-box A/B 103.6-104.5 -> 106.5-106.9
+        // samples/s, slot 17.6 -> 17.15 us (profiles/r04_task_order_ab.txt; the other FH blocks FIRST as well: no further gain).  (The order has no
+        // bearing on the arithmetic: a block's partial sums are addressed by its indices.)
+        {
+            std::vector<int> head, tail;
+            for (size_t i = 0; i < tasks.size(); i += 4) {
+                std::vector<int>& dst = (tasks[i + 1] == TK_FH && tasks[i + 2] == tasks[i + 3]) ? tail : head;
+                dst.insert(dst.end(), tasks.begin() + i, tasks.begin() + i + 4);
+            }
+            head.insert(head.end(), tail.begin(), tail.end());
+            tasks.swap(head);
+        }
         const int n_tasks = (int)(tasks.size() / 4);
         // tasks of the separable streaming kernel: as above, with FH_bb + FK_bb of a component paired (equal work per workgroup) -- when there
         // are more tasks than CUs.  On a small grid every task has a CU of its own and the kernel lasts as long as its longest workgroup: a
