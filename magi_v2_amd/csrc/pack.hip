@@ -201,7 +201,7 @@ int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double*
         // are more tasks than CUs.  On a small grid every task has a CU of its own and the kernel lasts as long as its longest workgroup: a
         // pair's 16 dependent steps would be that workgroup (N = 161, b = 80, 8 chains: option sep_pair_min = 0 forces the pairs for A/B).
         const bool pair_diag = n_tasks > h->opt.sep_pair_min;
-        std::vector<int> stasks;
+        std::vector<int> stasks, spairs;
         for (int i = 0; i < n_tasks; ++i) {
             const int d = tasks[4 * i], kind = tasks[4 * i + 1], bi = tasks[4 * i + 2], bj = tasks[4 * i + 3];
             int partner = -1;
@@ -211,8 +211,12 @@ int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double*
                     if (tasks[4 * j] == d && tasks[4 * j + 1] == TK_FK && tasks[4 * j + 2] == bi && tasks[4 * j + 3] == bi) { partner = j; break; }
             }
             const int e[8] = {d, kind, bi, bj, i, partner, TK_FK, 0};
-            stasks.insert(stasks.end(), e, e + 8);
+            // (the pairs stream two blocks: they are dispatched FIRST -- with the diagonal FH blocks at the end of `tasks` they would start last
+            //  and end the launch 0.5 us later, measured)
+            if (partner >= 0) spairs.insert(spairs.end(), e, e + 8);
+            else stasks.insert(stasks.end(), e, e + 8);
         }
+        stasks.insert(stasks.begin(), spairs.begin(), spairs.end());
         const int n_stasks = (int)(stasks.size() / 8);
         const size_t n_task_ints = tasks.size();
         tasks.insert(tasks.end(), stasks.begin(), stasks.end());
