@@ -68,8 +68,12 @@ def test_stream_kernels_spill_no_vector_register(tmp_path):
         seen += 1
         spills = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
         occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
         assert spills == 0, (name, spills)
         assert occ >= 3, (name, occ)
+        # round 4: no scratch reservation at all (64 B/lane until then: a `LeafPlan` kept in memory by an aggregate copy, and the spill slot of a
+        # callee-saved register in dual_averaging_eval -- decide.h: plan_store, the leaf function)
+        assert scratch == 0, (name, scratch)
     assert seen >= 6
 
 
