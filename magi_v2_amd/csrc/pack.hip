@@ -182,19 +182,36 @@ int magi_pack_matrices(magi_handle* h, int N, int D, int bandsize, const double*
                         if (std::abs(bi - bj) > wb) continue;
                         tasks.push_back(d); tasks.push_back(kind); tasks.push_back(bi); tasks.push_back(bj);
                     }
-        // Launch order = task order, and the hardware fills the CUs two workgroups at a time: with 544 blocks on 256 CUs (N = 1024, dense) the LAST
-        // 32 tasks become the third workgroup of 32 CUs, which then stream 384 KB instead of 256 KB and end last (profiles/r04_wg_trace_1chain.txt).
-        // The diagonal blocks of FH are the lightest tasks (row-type product only, no theta' in front): they go to the end of the list: same-box A/B 103.6-104.5 -> 106.5-106.9
-        // samples/s, slot 17.6 -> 17.15 us (profiles/r04_task_order_ab.txt; the other FH blocks FIRST as well: no further gain).  (The order has no
-        // bearing on the arithmetic: a block's partial sums are addressed by its indices.)
+        // Launch order = task order, and the order decides which tasks share a CU: the hardware deals the workgroups of a launch that is resident all
+        // at once round-robin -- launch indices w, w + C, w + 2 C land on the same CU (C CUs; tools/exp_wg_trace.py) -- so with 1 + 544 workgroups on
+        // 256 CUs (N = 1024, dense) the first 33 CUs host THREE of them, stream 384 KB instead of 256 KB and end last (profiles/r04_wg_trace_1chain.txt:
+        // 1.0 us after the others).  The blocks of FH are the light tasks (no theta' in front; the diagonal ones a row-type product only: 8.1 against 8.8 us
+        // of life): they take the launch positions of those CUs in every round, the rest keeps its order.  Same-box A/Bs (profiles/r04_task_order_ab.txt):
+        // diagonal FH blocks last 103.6-104.5 -> 106.5-106.9 samples/s; light tasks on all three positions of the triple CUs 108.9-109.3, slot 17.6 -> 16.8 us
+        // (the exact variants of the pattern agree within the noise; this one measured best).  The order has no bearing on the arithmetic: a block's
+        // partial sums are addressed by its indices.  Only launches of exactly three rounds are re-ordered: fewer have no third workgroups, more are
+        // placed dynamically.
         {
-            std::vector<int> head, tail;
-            for (size_t i = 0; i < tasks.size(); i += 4) {
-                std::vector<int>& dst = (tasks[i + 1] == TK_FH && tasks[i + 2] == tasks[i + 3]) ? tail : head;
-                dst.insert(dst.end(), tasks.begin() + i, tasks.begin() + i + 4);
+            int ncu = 0;
+            (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+            const int T = (int)(tasks.size() / 4) + 1;                       // + the decision workgroup (launch index 0)
+            const int rounds = ncu > 0 ? (T + ncu - 1) / ncu : 0, R = ncu > 0 ? T % ncu : 0;
+            if (rounds == 3 && R > 1) {
+                std::vector<int> heavy, off, diag;
+                for (size_t i = 0; i < tasks.size(); i += 4) {
+                    std::vector<int>& dst = tasks[i + 1] != TK_FH ? heavy : (tasks[i + 2] == tasks[i + 3] ? diag : off);
+                    dst.insert(dst.end(), tasks.begin() + i, tasks.begin() + i + 4);
+                }
+                std::vector<int> out;
+                auto take = [&](std::vector<int>& src, size_t& pos, size_t n) { const size_t m = std::min(n * 4, src.size() - pos); out.insert(out.end(), src.begin() + pos, src.begin() + pos + m); pos += m; };
+                size_t ph = 0, po = 0, pd = 0;
+                const size_t r = (size_t)R - 1, c = (size_t)ncu;
+                take(off, po, r); take(heavy, ph, c - r);                    // round 0: the triple CUs' first workgroups are light
+                take(diag, pd, r); take(off, po, r);                         // round 1: their second ones the lightest; (then one more stretch of light ones: measured)
+                take(heavy, ph, heavy.size());                               // everything heavy
+                take(off, po, off.size()); take(diag, pd, diag.size());      // round 2 = the tail of the launch: light
+                tasks.swap(out);
             }
-            head.insert(head.end(), tail.begin(), tail.end());
-            tasks.swap(head);
         }
         const int n_tasks = (int)(tasks.size() / 4);
         // tasks of the separable streaming kernel: as above, with FH_bb + FK_bb of a component paired (equal work per workgroup) -- when there

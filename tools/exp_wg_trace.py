@@ -29,7 +29,12 @@ fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
 # the task table as pack.hip builds it
 D, nb = 4, (N + 127) // 128
 tasks = [(d, k, bi, bj) for d in range(D) for k in range(3) for bi in range(nb) for bj in range(nb) if k == 2 or bj <= bi]
-tasks = [t for t in tasks if not (t[1] == 0 and t[2] == t[3])] + [t for t in tasks if t[1] == 0 and t[2] == t[3]]      # (the diagonal FH blocks go last)
+# (pack.hip's launch order for a three-round launch: light FH tasks on the launch positions of the CUs that host three workgroups)
+C_, T_ = 256, len(tasks) + 1
+if (T_ + C_ - 1) // C_ == 3 and T_ % C_ > 1:
+    r_ = T_ % C_ - 1
+    heavy = [t for t in tasks if t[1] != 0]; off = [t for t in tasks if t[1] == 0 and t[2] != t[3]]; diag = [t for t in tasks if t[1] == 0 and t[2] == t[3]]
+    tasks = off[:r_] + heavy[:C_ - r_] + diag[:r_] + off[r_:2 * r_] + heavy[C_ - r_:] + off[2 * r_:] + diag[r_:]
 sep = n >= 3 and len(tasks) * ((n + 1) // 2) > 320
 if sep and len(tasks) > 256:
     st = [(d, k, bi, bj, (k != 2 and bi == bj)) for (d, k, bi, bj) in tasks if not (k == 1 and bi == bj)]
