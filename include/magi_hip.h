@@ -248,7 +248,7 @@ int magi_theta_init(magi_handle* h, int drift_id, int P, const double* Xhat, con
 int magi_time_gradient(magi_handle* h, int n_chains, int reps, double* total_ms_per_eval, double* phase_ms);
 
 /* Of the last magi_sampler_run: leapfrog slots (kernel pairs [k_stream, k_point]) issued before every chain had finished --
- * counted on the device -- and graph launches (of 64 slots each) the host made.  A slot advances every unfinished chain by one
+ * counted on the device -- and graph launches (of 128 slots each; MAGI_GRAPH_SLOTS) the host made.  A slot advances every unfinished chain by one
  * leaf or one set-up step, so slots_issued >= the leapfrogs of the busiest chain. */
 int magi_sampler_run_stats(magi_handle* h, int64_t* slots_issued, int64_t* graphs_launched);
 

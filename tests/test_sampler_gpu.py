@@ -236,14 +236,14 @@ def test_one_kernel_family_makes_a_chain_independent_of_its_batch_size(monkeypat
 
 def test_slot_budget_exit_reports_the_stuck_chain_and_the_handle_stays_usable(monkeypatch):
     """The pump of magi_sampler_run is bounded: a run that outlives its slot budget returns MAGI_E_STATE naming the chain's
-    k / phase / depth (csrc/capi.hip).  Forced here with a one-graph budget (64 slots) on transitions that need more; the
+    k / phase / depth (csrc/capi.hip).  Forced here with a one-graph budget (128 slots) on transitions that need more; the
     handle is then re-initialised and runs the same chain to completion."""
     from magi_v2_amd.engine import MagiHipError
     g = load_g4("seir4_N81")
     pr = problem_from_g4(g, None)
     eng = engine_for(pr, None)
     X0, s0, t0 = orc.initial_state(g["Xhat_init"], g["sigma_sqs_init"], np.ones(pr.P), pr.LB)
-    cfg = eng.default_cfg(num_results=2, num_burnin_steps=6, step_size=1e-3)        # (a small first step: deep trees, > 64 slots)
+    cfg = eng.default_cfg(num_results=2, num_burnin_steps=6, step_size=1e-3)        # (a small first step: deep trees, > 128 slots)
     eng.sampler_init(cfg, X0, s0, t0, seed=1234)
     eng.set_option("slot_budget_graphs", 1)
     with pytest.raises(MagiHipError) as ei:
@@ -256,7 +256,7 @@ def test_slot_budget_exit_reports_the_stuck_chain_and_the_handle_stays_usable(mo
     lf, _ = eng.sampler_run(8)
     slots, graphs = eng.sampler_run_stats()
     d = eng.sampler_diag()
-    assert lf == d.leapfrogs_taken.sum() and lf > 64 and slots >= lf and graphs * 64 >= slots
+    assert lf == d.leapfrogs_taken.sum() and lf > 128 and slots >= lf and graphs * 128 >= slots
     _, _, otp, _, _ = orc.sample_chain(pr, g["Xhat_init"], g["sigma_sqs_init"], np.ones(pr.P), 2, 6, seed=1234, step_size=1e-3)
     np.testing.assert_allclose(eng.sampler_samples()[2][0], otp, rtol=1e-7, atol=1e-9)
     eng.close()
